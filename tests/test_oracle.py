@@ -1,0 +1,244 @@
+"""Pins the CPU oracle (oracle/mtp_oracle.c) and the table generator with checks that
+share no code with either: closed forms, an einsum evaluation from the mathematical
+definition, finite differences and symmetry invariants.  (The reference has no tests or
+fixtures of its own to borrow -- SURVEY.md section 4 -- and cannot be compiled in this image;
+the oracle header says "parity unpinned".)
+"""
+import numpy as np
+import pytest
+
+from lammps_mtp_kokkos_amd import mtpgen
+from lammps_mtp_kokkos_amd.driver import periodic_system
+from oracle.pyoracle import Oracle
+
+import _definition as defn
+
+
+def _make(tmp, level, species=1, mvs=None, seed=12345, name=None, damp=0.25, template8=False):
+    tab = mtpgen.level8_template() if template8 else mtpgen.build_table(level)
+    pot = mtpgen.random_potential(tab, species, seed, damp=damp)
+    if mvs:
+        mtpgen.add_selection_state(pot, mvs)
+    path = str(tmp / (name or "L%d_s%d_%s.mtp" % (level, species, mvs)))
+    mtpgen.write_mtp(pot, path)
+    return pot, path
+
+
+def _system(ncell=(3, 3, 3), species=1, seed=777, jitter=0.05, list_cutoff=7.0):
+    pos, box = mtpgen.bcc_lattice(*ncell, jitter=jitter, seed=seed)
+    rng = np.random.default_rng(5)
+    types = rng.integers(1, species + 1, size=len(pos)).astype(np.int32)
+    return periodic_system(pos, box, types, list_cutoff)
+
+
+def test_generator_sizes_match_survey_enumeration():
+    # SURVEY.md App. C table (S complete, B) -- independent brute-force count there.
+    expect = {2: (1, 1), 4: (2, 1), 6: (5, 5), 8: (9, 11), 10: (17, 25), 12: (32, 46), 14: (61, 81),
+              16: (116, 130)}
+    for L, (S, B) in expect.items():
+        t = mtpgen.build_table(L)
+        assert (len(t.mapping), len(t.basic)) == (S, B), L
+
+
+def test_generator_level8_is_known_answer():
+    t = mtpgen.build_table(8)
+    k = mtpgen.LEVEL8_KNOWN_ANSWER
+    assert t.basic == k["basic"]
+    assert sorted(t.times) == sorted(k["times"])
+    assert t.mapping == k["mapping"] and t.nmoments == k["nmoments"]
+
+
+def test_parser_roundtrip(tmp_path):
+    pot, path = _make(tmp_path, 10, species=2, mvs="nbh")
+    o = Oracle(path, selection=True)
+    s = o.sizes
+    t = pot.table
+    assert (s["B"], s["T"], s["S"], s["A"], s["Mu"], s["R"], s["Sp"]) == \
+        (len(t.basic), len(t.times), len(t.mapping), t.nmoments, t.radial_funcs, 8, 2)
+    assert s["C"] == pot.coeff_count
+    np.testing.assert_array_equal(o.arr("alpha_index_basic", 4 * s["B"], np.int64).reshape(-1, 4), np.array(t.basic))
+    np.testing.assert_array_equal(o.arr("alpha_index_times", 4 * s["T"], np.int64).reshape(-1, 4), np.array(t.times))
+    np.testing.assert_allclose(o.arr("radial_basis_coeffs", pot.radial_coeffs.size), pot.radial_coeffs.ravel(), rtol=1e-15)
+    np.testing.assert_allclose(o.arr("linear_coeffs", s["S"]), pot.moment_coeffs, rtol=1e-15)
+    np.testing.assert_array_equal(o.arr("inverse_active_set", s["C"] ** 2), pot.inverse_active_set.ravel())
+    assert o.m.configuration_mode == 0
+
+
+def test_parser_rejects_bad_files(tmp_path):
+    pot, path = _make(tmp_path, 8)
+    txt = open(path).read()
+    for bad, what in [(txt.replace("MTP\n", "XTP\n", 1), "Only MTP"),
+                      (txt.replace("version = 1.1.0", "version = 1.0.0"), "version"),
+                      (txt.replace("RBChebyshev", "RBFoo"), "radial basis"),
+                      (txt.replace("{1, 0, 0, 0}}", "{0, 0, 0, 0}}"), "Wrong number of radial")]:
+        p = tmp_path / "bad.mtp"
+        p.write_text(bad)
+        with pytest.raises(RuntimeError, match=what):
+            Oracle(str(p))
+    with pytest.raises(RuntimeError, match="No selection state"):
+        Oracle(path, selection=True)
+
+
+def test_chebyshev_closed_form(tmp_path):
+    pot, path = _make(tmp_path, 8)
+    o = Oracle(path)
+    h = 1e-6
+    for r in np.linspace(2.0, 5.0, 13):
+        v, d = o.radial_basis(r)
+        xi = (2 * r - 7.0) / 3.0
+        want = np.array([defn.chebyshev_T(k, xi) for k in range(8)]) * (r - 5.0) ** 2
+        np.testing.assert_allclose(v, want, rtol=1e-12, atol=1e-13)
+        vp, _ = o.radial_basis(r + h)
+        vm, _ = o.radial_basis(r - h)
+        np.testing.assert_allclose(d, (vp - vm) / (2 * h), rtol=1e-6, atol=1e-7)
+    v, d = o.radial_basis(5.0)          # value and slope vanish at the cutoff
+    assert np.abs(v).max() == 0 and np.abs(d).max() == 0
+
+
+def test_level8_energy_from_hand_written_definition(tmp_path):
+    pot, path = _make(tmp_path, 8, species=2, template8=True, name="L8tmpl.mtp")
+    sysm = _system(species=2)
+    res = Oracle(path).compute(sysm.x, sysm.types, sysm.ilist, sysm.first, sysm.neigh)
+    need = [(0, 0), (1, 0), (0, 1), (0, 2)]
+    for i in range(sysm.nlocal):
+        js = sysm.neigh[sysm.first[i]:sysm.first[i + 1]]
+        rv = sysm.x[js] - sysm.x[i]
+        m = (rv ** 2).sum(1) <= 25.0
+        zi = sysm.types[i] - 1
+        ten = defn.site_tensors(pot, rv[m], zi, sysm.types[js[m]] - 1, need)
+        e = pot.species_coeffs[zi] + defn.level8_basis(ten) @ pot.moment_coeffs
+        assert abs(e - res["eatom"][i]) < 1e-11 * max(1.0, abs(e))
+
+
+@pytest.mark.parametrize("level,species", [(10, 2), (12, 1), (16, 1)])
+def test_generated_tables_match_einsum_definition(tmp_path, level, species):
+    pot, path = _make(tmp_path, level, species=species)
+    sysm = _system(ncell=(2, 2, 2) if level == 16 else (3, 3, 3), species=species)
+    res = Oracle(path).compute(sysm.x, sysm.types, sysm.ilist, sysm.first, sysm.neigh)
+    E, _ = defn.site_energies(pot, pot.table.graphs, sysm)
+    np.testing.assert_allclose(res["eatom"][:sysm.nlocal], E, rtol=2e-11, atol=1e-11)
+    assert abs(res["energy"] - E.sum()) < 1e-10 * max(1.0, abs(E.sum()))
+
+
+@pytest.mark.parametrize("level,species", [(8, 2), (12, 1)])
+def test_forces_are_minus_gradient_and_sum_to_zero(tmp_path, level, species):
+    pot, path = _make(tmp_path, level, species=species)
+    o = Oracle(path)
+    pos, box = mtpgen.bcc_lattice(3, 3, 3)
+    rng = np.random.default_rng(5)
+    types = rng.integers(1, species + 1, size=len(pos)).astype(np.int32)
+
+    def energy_forces(p):
+        s = periodic_system(p, box, types, 7.0)
+        r = o.compute(s.x, s.types, s.ilist, s.first, s.neigh)
+        return r["energy"], s.fold_forces(r["f"]), r, s
+
+    E, F, r, s = energy_forces(pos)
+    assert abs(E - r["eatom"][:s.nlocal].sum()) < 1e-10 * max(1, abs(E))
+    assert np.abs(F.sum(0)).max() < 1e-10 * max(1.0, np.abs(F).max())
+    h = 1e-5
+    for (a, c) in [(0, 0), (7, 1), (20, 2), (53, 0)]:
+        pp = pos.copy(); pp[a, c] += h
+        pm = pos.copy(); pm[a, c] -= h
+        fd = -(energy_forces(pp)[0] - energy_forces(pm)[0]) / (2 * h)
+        assert abs(fd - F[a, c]) < 2e-7 * max(1.0, np.abs(F).max())
+
+
+def test_virial_is_strain_derivative(tmp_path):
+    pot, path = _make(tmp_path, 8)
+    o = Oracle(path)
+    pos, box = mtpgen.bcc_lattice(3, 3, 3)
+
+    def run(eps):
+        s = periodic_system(pos * (1 + eps), box * (1 + eps), None, 7.0)
+        return o.compute(s.x, s.types, s.ilist, s.first, s.neigh), s
+
+    r0, s0 = run(0.0)
+    h = 1e-6
+    dE = (run(h)[0]["energy"] - run(-h)[0]["energy"]) / (2 * h)
+    # LAMMPS sign: virial_ab = sum r_a f_b  ->  dE/d(eps) = -(vxx+vyy+vzz)
+    assert abs(dE + r0["virial"][:3].sum()) < 1e-6 * max(1.0, abs(dE))
+    np.testing.assert_allclose(r0["vatom"][:s0.nlocal].sum(0), r0["virial"], rtol=1e-12, atol=1e-12)
+
+
+def test_rotation_translation_permutation_invariance(tmp_path):
+    pot, path = _make(tmp_path, 10)
+    o = Oracle(path)
+    s = _system()
+    r0 = o.compute(s.x, s.types, s.ilist, s.first, s.neigh)
+    # random rotation about the origin + translation of every coordinate (list is index-based)
+    rng = np.random.default_rng(3)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] *= -1
+    r1 = o.compute(s.x @ q.T + np.array([0.3, -1.2, 4.0]), s.types, s.ilist, s.first, s.neigh)
+    np.testing.assert_allclose(r1["eatom"], r0["eatom"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(r1["f"], r0["f"] @ q.T, rtol=1e-10, atol=1e-11)
+    # shuffle the order of each atom's neighbours
+    neigh = s.neigh.copy()
+    for i in range(s.nlocal):
+        rng.shuffle(neigh[s.first[i]:s.first[i + 1]])
+    r2 = o.compute(s.x, s.types, s.ilist, s.first, neigh)
+    np.testing.assert_allclose(r2["f"], r0["f"], rtol=1e-11, atol=1e-12)
+
+
+def test_species_outside_potential_is_an_error(tmp_path):
+    pot, path = _make(tmp_path, 8)
+    s = _system()
+    t = s.types.copy()
+    t[3] = 2
+    with pytest.raises(RuntimeError):
+        Oracle(path).compute(s.x, t, s.ilist, s.first, s.neigh)
+
+
+def test_extrapolation_candidate_vector_is_dE_dtheta(tmp_path):
+    """c = dE_i/dtheta (pair_mtp_extrapolation.cpp:235-252, 323-329): linear part =
+    basis values; radial part checked by finite differences on the coefficient file;
+    E, F identical to the plain path; grade = max|A^-1 c|."""
+    pot, path = _make(tmp_path, 10, species=2, mvs="nbh")
+    s = _system(ncell=(2, 2, 2), species=2)
+    o = Oracle(path, selection=True)
+    plain = o.compute(s.x, s.types, s.ilist, s.first, s.neigh)
+    ext = o.compute(s.x, s.types, s.ilist, s.first, s.neigh, extrapolation=True)
+    np.testing.assert_array_equal(ext["f"], plain["f"])
+    assert ext["energy"] == plain["energy"]
+    # per-atom candidate vector: run one atom at a time
+    _, Bv = defn.site_energies(pot, pot.table.graphs, s)
+    nrad = 4 * pot.table.radial_funcs * 8
+    Ainv = pot.inverse_active_set
+    for i in [0, 5, 11]:
+        one = o.compute(s.x, s.types, s.ilist[i:i + 1], np.array([0, s.first[i + 1] - s.first[i]], dtype=np.int32),
+                        s.neigh[s.first[i]:s.first[i + 1]], extrapolation=True)
+        c = one["coeff_ders"]
+        np.testing.assert_allclose(c[nrad + 2:], Bv[i], rtol=1e-10, atol=1e-11)
+        sp = np.zeros(2); sp[s.types[i] - 1] = 1
+        np.testing.assert_array_equal(c[nrad:nrad + 2], sp)
+        assert abs(np.abs(Ainv @ c).max() - ext["grades"][i]) < 1e-12 * max(1, ext["grades"][i])
+        # radial block by finite differences of E_i w.r.t. two coefficients
+        for flat in [3, nrad - 5, (s.types[i] - 1) * 2 * pot.table.radial_funcs * 8 + 9]:
+            h = 1e-6
+            es = []
+            for sign in (+1, -1):
+                p2 = mtpgen.random_potential(pot.table, 2, 12345)
+                p2.radial_coeffs = pot.radial_coeffs.copy()
+                p2.radial_coeffs.reshape(-1)[flat] += sign * h
+                pth = str(tmp_path / "pert.mtp")
+                mtpgen.write_mtp(p2, pth)
+                es.append(Oracle(pth).compute(s.x, s.types, s.ilist[i:i + 1],
+                                              np.array([0, s.first[i + 1] - s.first[i]], dtype=np.int32),
+                                              s.neigh[s.first[i]:s.first[i + 1]])["eatom"][i])
+            fd = (es[0] - es[1]) / (2 * h)
+            assert abs(fd - c[flat]) < 1e-6 * max(1.0, abs(c[flat]))
+    assert ext["max_grade"] == ext["grades"][:s.nlocal].max()
+
+
+def test_configuration_mode_grade(tmp_path):
+    pot, path = _make(tmp_path, 8, mvs="cfg")
+    s = _system(ncell=(2, 2, 2))
+    o = Oracle(path, selection=True)
+    assert o.m.configuration_mode == 1
+    r = o.compute(s.x, s.types, s.ilist, s.first, s.neigh, extrapolation=True, natoms=s.nlocal)
+    c = r["coeff_ders"]
+    assert c[2 * 8] == s.nlocal                    # species slot counts atoms
+    want = np.abs(pot.inverse_active_set @ c).max() / s.nlocal
+    assert abs(want - r["max_grade"]) < 1e-12 * want
