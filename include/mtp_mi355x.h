@@ -1,0 +1,146 @@
+/* libmtp_mi355x -- C ABI of the MI355X-native MTP pair-style compute path.
+ *
+ * This is the drop-in boundary: plain C types, opaque handles, int status
+ * returns, no exceptions across the boundary.  Each entry point names the reference
+ * interface (file:line relative to /root/reference) it stands in for; INTEGRATION.md
+ * shows the LAMMPS `Pair` subclass / plugin stub that binds them.
+ *
+ * Threading: one context per rank/GPU; calls on one context must be serialised by the
+ * caller (the reference is not re-entrant either: member scratch buffers,
+ * LAMMPS/ML-MTP/pair_mtp.h:70-83).  Device work is ordered on the stream given to the
+ * `_device` entry points (the context's own stream otherwise).
+ */
+#ifndef MTP_MI355X_H
+#define MTP_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTP_MI355X_ABI_VERSION 1
+
+/* status codes (the reference aborts through error->one/all, pair_mtp.cpp:92,354-358;
+ * the adapter turns a non-zero status + mtp_last_error() into error->all) */
+enum {
+  MTP_OK = 0,
+  MTP_ERR_IO = -2,          /* cannot open / short read */
+  MTP_ERR_EOF = -3,
+  MTP_ERR_FORMAT = -4,      /* not "MTP" / wrong version */
+  MTP_ERR_PARSE = -5,       /* keyword or number missing */
+  MTP_ERR_UNSUPPORTED = -6, /* magnetic basis, unknown radial basis */
+  MTP_ERR_TABLE = -7,       /* inconsistent alpha tables */
+  MTP_ERR_SELECTION = -8,   /* #MVS block missing or malformed */
+  MTP_ERR_MODE = -9,        /* energy_weight + site_en_weight > 1 */
+  MTP_ERR_ARG = -20,
+  MTP_ERR_DEVICE = -21,     /* HIP runtime failure, no device, wrong architecture */
+  MTP_ERR_SPECIES = -22,    /* atom type outside the potential (pair_mtp.cpp:91-93,116-118) */
+  MTP_ERR_STATE = -23,      /* e.g. compute before set_neighbors, grades without #MVS */
+  MTP_ERR_LIMIT = -24       /* table or neighbour count beyond what one wave's LDS holds */
+};
+
+/* eflag / vflag bits follow LAMMPS (pair.h: ENERGY_GLOBAL 1, ENERGY_ATOM 2,
+ * VIRIAL_PAIR 1, VIRIAL_FDOTR 2, VIRIAL_ATOM 4).  PairMTP::compute tests the raw vflag
+ * (pair_mtp.cpp:257): any non-zero vflag tallies the global virial, bit 4 also vatom. */
+#define MTP_ENERGY_GLOBAL 1
+#define MTP_ENERGY_ATOM 2
+#define MTP_VIRIAL_ATOM 4
+
+/* kernel variant: the reference exposes two GPU styles, `mtp/kk` (thread-parallel,
+ * KOKKOS/pair_mtp_kokkos.h:20-22) and `mtp/small/kk` (block-parallel,
+ * KOKKOS/pair_mtps_kokkos.h:20-22).  Both map onto one wavefront-per-atom design here;
+ * the variant only picks how many wavefronts share a workgroup. */
+enum { MTP_VARIANT_AUTO = 0, MTP_VARIANT_LARGE = 1, MTP_VARIANT_SMALL = 2 };
+
+typedef struct mtp_potential mtp_potential; /* parsed MLIP-3 file: PairMTP model state, pair_mtp.h:47-83 */
+typedef struct mtp_context mtp_context;     /* one GPU: device tables, neighbour list, workspaces */
+
+typedef struct mtp_potential_info {
+  int32_t species_count;
+  int32_t radial_basis_size;       /* R  */
+  int32_t radial_func_count;       /* Mu */
+  int32_t alpha_moment_count;      /* A  */
+  int32_t alpha_index_basic_count; /* B  */
+  int32_t alpha_index_times_count; /* T  */
+  int32_t alpha_scalar_count;      /* S  */
+  int32_t max_alpha_index_basic;   /* P  */
+  int32_t coeff_count;             /* C = Sp^2 Mu R + Sp + S (pair_mtp_extrapolation.cpp:533) */
+  int32_t has_selection;           /* a #MVS_v1.1 block was read */
+  int32_t configuration_mode;      /* energy_weight == 1 (pair_mtp_extrapolation.cpp:605) */
+  int32_t product_levels;          /* dependency levels of the times table (native schedule) */
+  double scaling;
+  double min_cutoff;
+  double max_cutoff;               /* what PairMTP::init_one returns, pair_mtp.cpp:325-330 */
+} mtp_potential_info;
+
+/* PairMTP::read_file (pair_mtp.cpp:335-570) + RadialMTPBasis::ReadBasisProperties
+ * (mtp_radial_basis.cpp:59-102); with want_selection != 0 also
+ * PairMTPExtrapolation::read_file (pair_mtp_extrapolation.cpp:528-612).  Host only. */
+int mtp_potential_load(const char *path, int want_selection, mtp_potential **out, char *err, int errlen);
+void mtp_potential_free(mtp_potential *pot);
+int mtp_potential_get_info(const mtp_potential *pot, mtp_potential_info *info);
+/* copies of the parsed tables for inspection (sizes from get_info); any pointer may be NULL */
+int mtp_potential_get_tables(const mtp_potential *pot, int32_t *alpha_index_basic /*[B][4]*/,
+                             int32_t *alpha_index_times /*[T][4]*/, int32_t *alpha_moment_mapping /*[S]*/,
+                             double *radial_coeffs /*[Sp*Sp*Mu*R]*/, double *species_coeffs /*[Sp]*/,
+                             double *moment_coeffs /*[S]*/, double *inverse_active_set /*[C*C]*/);
+
+/* The device copies made in PairMTPKokkos::settings (KOKKOS/pair_mtp_kokkos.cpp:108-174).
+ * Fails with MTP_ERR_DEVICE when no gfx950 device is usable: there is no CPU fallback. */
+int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **out, char *err, int errlen);
+void mtp_context_destroy(mtp_context *ctx);
+const char *mtp_last_error(const mtp_context *ctx);
+int mtp_context_set_variant(mtp_context *ctx, int variant);
+
+/* The neighbour list PairMTP::compute reads (pair_mtp.cpp:81-85): call after every
+ * LAMMPS re-neighbouring.  `firstneigh[i]` is indexed by atom index i = ilist[ii], as in
+ * LAMMPS; entries are masked with NEIGHMASK on the device. */
+int mtp_set_neighbors(mtp_context *ctx, int inum, const int *ilist, const int *numneigh,
+                      const int *const *firstneigh, int nall);
+/* Same list in CSR form: neighbours of ilist[ii] are neigh[first[ii] .. first[ii+1]). */
+int mtp_set_neighbors_csr(mtp_context *ctx, int inum, const int *ilist, const int *first, const int *neigh,
+                          int nall);
+/* CSR arrays already resident in HBM (no copy; must stay valid until replaced). */
+int mtp_set_neighbors_device(mtp_context *ctx, int inum, const int *d_ilist, const int *d_first,
+                             const int *d_neigh, int nall, int max_numneigh);
+
+/* PairMTP::compute (pair_mtp.cpp:72-280) and, with grade_flag != 0,
+ * PairMTPExtrapolation::compute (pair_mtp_extrapolation.cpp:68-382), on host arrays laid
+ * out as LAMMPS lays them out: x, f [nall][3]; type [nall] 1-based; eatom [nall];
+ * vatom [nall][6].  f, virial and vatom ACCUMULATE, eatom[i] is assigned for i in ilist,
+ * *energy accumulates (eng_vdwl), exactly as in the reference.  grades[i] (neighbourhood
+ * mode) is assigned for i in ilist; *max_grade is this rank's maximum (neighbourhood) or
+ * is left to mtp_cfg_grade (configuration mode, where coeff_ders[C] receives this rank's
+ * sum_i dE_i/dtheta for the caller to all-reduce, pair_mtp_extrapolation.cpp:369).
+ * Unused outputs may be NULL.  Copies go over PCIe; use the _device form to avoid them. */
+int mtp_compute(mtp_context *ctx, const double *x, const int *type, int eflag, int vflag, int grade_flag,
+                double *f, double *eatom, double *vatom, double *energy, double *virial /*[6]*/,
+                double *grades, double *max_grade, double *coeff_ders);
+
+/* Same, device pointers, asynchronous on `stream` (a hipStream_t, NULL = context stream).
+ * d_ev[7] accumulates {energy, virial xx,yy,zz,xy,xz,yz}; d_max_grade[1] is max-updated
+ * (caller zeroes); d_coeff_ders[C] accumulates.  The atom-type error is reported by the next
+ * mtp_synchronize(). */
+int mtp_compute_device(mtp_context *ctx, void *stream, const double *d_x, const int *d_type, int eflag,
+                       int vflag, int grade_flag, double *d_f, double *d_eatom, double *d_vatom,
+                       double *d_ev, double *d_grades, double *d_max_grade, double *d_coeff_ders);
+int mtp_synchronize(mtp_context *ctx, void *stream);
+
+/* PairMTPExtrapolation::calculate_extrapolation_grade (pair_mtp_extrapolation.cpp:347-358)
+ * for configuration mode: max_i |sum_j coeff_ders[j] A^-1[i][j]| on the host (C^2 flops,
+ * once per step after the cross-rank sum). */
+int mtp_cfg_grade(const mtp_potential *pot, const double *coeff_ders, double *grade);
+
+/* introspection for benchmarks: LDS bytes per wavefront, wavefronts per workgroup, grid */
+int mtp_context_launch_info(const mtp_context *ctx, int32_t *lds_bytes_per_wave, int32_t *waves_per_block,
+                            int32_t *grid_blocks, int32_t *neighbor_tile);
+/* last kernel time of the dominant kernel in ms, measured with HIP events on the launch
+ * stream (enable with mtp_context_set_timing(ctx, 1); costs one event pair per call) */
+int mtp_context_set_timing(mtp_context *ctx, int enable);
+int mtp_context_last_kernel_ms(mtp_context *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,218 @@
+"""ctypes binding of libmtp_mi355x.so (include/mtp_mi355x.h) for tests, bench and the
+multi-GPU driver.  There is no fallback: a missing library or a missing gfx950 device
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmtp_mi355x.so")
+
+MTP_OK = 0
+ERR_NAMES = {-2: "IO", -3: "EOF", -4: "FORMAT", -5: "PARSE", -6: "UNSUPPORTED", -7: "TABLE",
+             -8: "SELECTION", -9: "MODE", -20: "ARG", -21: "DEVICE", -22: "SPECIES", -23: "STATE",
+             -24: "LIMIT"}
+VARIANT_AUTO, VARIANT_LARGE, VARIANT_SMALL = 0, 1, 2
+
+EXPORTS = [
+    "mtp_potential_load", "mtp_potential_free", "mtp_potential_get_info", "mtp_potential_get_tables",
+    "mtp_context_create", "mtp_context_destroy", "mtp_last_error", "mtp_context_set_variant",
+    "mtp_set_neighbors", "mtp_set_neighbors_csr", "mtp_set_neighbors_device", "mtp_compute",
+    "mtp_compute_device", "mtp_synchronize", "mtp_cfg_grade", "mtp_context_launch_info",
+    "mtp_context_set_timing", "mtp_context_last_kernel_ms",
+]
+
+
+class MtpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmtp_mi355x: %s (%d): %s" % (ERR_NAMES.get(code, "?"), code, msg))
+        self.code = code
+
+
+class PotentialInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "species_count", "radial_basis_size", "radial_func_count", "alpha_moment_count",
+        "alpha_index_basic_count", "alpha_index_times_count", "alpha_scalar_count",
+        "max_alpha_index_basic", "coeff_count", "has_selection", "configuration_mode",
+        "product_levels")] + [("scaling", C.c_double), ("min_cutoff", C.c_double), ("max_cutoff", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.mtp_last_error.restype = C.c_char_p
+        for n in EXPORTS:
+            getattr(L, n)           # AttributeError if the ABI drifted
+        for n in EXPORTS:
+            if n not in ("mtp_last_error", "mtp_potential_free", "mtp_context_destroy"):
+                getattr(L, n).restype = C.c_int
+        L.mtp_potential_free.restype = None
+        L.mtp_context_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def _np(a, ty):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ty))
+
+
+def _ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Potential:
+    def __init__(self, path, selection=False):
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = lib().mtp_potential_load(os.fsencode(path), int(selection), C.byref(self.h), err, 512)
+        if rc:
+            raise MtpError(rc, err.value.decode())
+        self.info = PotentialInfo()
+        lib().mtp_potential_get_info(self.h, C.byref(self.info))
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mtp_potential_free(self.h)
+            self.h = None
+
+    @property
+    def sizes(self):
+        i = self.info
+        return dict(Sp=i.species_count, R=i.radial_basis_size, Mu=i.radial_func_count, A=i.alpha_moment_count,
+                    B=i.alpha_index_basic_count, T=i.alpha_index_times_count, S=i.alpha_scalar_count,
+                    P=i.max_alpha_index_basic, C=i.coeff_count, levels=i.product_levels)
+
+    def tables(self):
+        i = self.info
+        out = dict(
+            alpha_index_basic=np.zeros((i.alpha_index_basic_count, 4), np.int32),
+            alpha_index_times=np.zeros((i.alpha_index_times_count, 4), np.int32),
+            alpha_moment_mapping=np.zeros(i.alpha_scalar_count, np.int32),
+            radial_coeffs=np.zeros(i.species_count ** 2 * i.radial_func_count * i.radial_basis_size),
+            species_coeffs=np.zeros(i.species_count), moment_coeffs=np.zeros(i.alpha_scalar_count))
+        inv = np.zeros((i.coeff_count, i.coeff_count)) if i.has_selection else None
+        rc = lib().mtp_potential_get_tables(
+            self.h, _np(out["alpha_index_basic"], C.c_int32), _np(out["alpha_index_times"], C.c_int32),
+            _np(out["alpha_moment_mapping"], C.c_int32), _np(out["radial_coeffs"], C.c_double),
+            _np(out["species_coeffs"], C.c_double), _np(out["moment_coeffs"], C.c_double), _np(inv, C.c_double))
+        if rc:
+            raise MtpError(rc, "get_tables")
+        if inv is not None:
+            out["inverse_active_set"] = inv
+        return out
+
+    def cfg_grade(self, coeff_ders):
+        g = C.c_double(0)
+        c = np.ascontiguousarray(coeff_ders, dtype=np.float64)
+        rc = lib().mtp_cfg_grade(self.h, _np(c, C.c_double), C.byref(g))
+        if rc:
+            raise MtpError(rc, "cfg_grade")
+        return g.value
+
+
+class Context:
+    """One GPU context.  Host-array path: set_neighbors + compute.  Device path:
+    set_neighbors_device + compute_device with torch tensors."""
+
+    def __init__(self, pot: Potential, device=0):
+        self.pot = pot
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = lib().mtp_context_create(pot.h, int(device), C.byref(self.h), err, 512)
+        if rc:
+            raise MtpError(rc, err.value.decode())
+        self._keep = []
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mtp_context_destroy(self.h)
+            self.h = None
+
+    def _check(self, rc):
+        if rc:
+            raise MtpError(rc, lib().mtp_last_error(self.h).decode())
+
+    def set_variant(self, v):
+        self._check(lib().mtp_context_set_variant(self.h, int(v)))
+
+    def set_neighbors(self, ilist, first, neigh, nall):
+        ilist = np.ascontiguousarray(ilist, np.int32)
+        first = np.ascontiguousarray(first, np.int32)
+        neigh = np.ascontiguousarray(neigh, np.int32)
+        self.nall = int(nall)
+        self._check(lib().mtp_set_neighbors_csr(self.h, len(ilist), _np(ilist, C.c_int), _np(first, C.c_int),
+                                                _np(neigh, C.c_int), int(nall)))
+
+    def set_neighbors_lammps(self, ilist, numneigh, rows, nall):
+        """LAMMPS form: numneigh[i], firstneigh[i] indexed by atom id (rows: list of int32 arrays)."""
+        ilist = np.ascontiguousarray(ilist, np.int32)
+        numneigh = np.ascontiguousarray(numneigh, np.int32)
+        rows = [np.ascontiguousarray(r, np.int32) for r in rows]
+        arr = (C.POINTER(C.c_int) * len(rows))(*[_np(r, C.c_int) for r in rows])
+        self.nall = int(nall)
+        self._check(lib().mtp_set_neighbors(self.h, len(ilist), _np(ilist, C.c_int), _np(numneigh, C.c_int), arr,
+                                            int(nall)))
+
+    def set_neighbors_device(self, ilist_t, first_t, neigh_t, nall, max_numneigh):
+        self._keep = [ilist_t, first_t, neigh_t]
+        self.nall = int(nall)
+        self._check(lib().mtp_set_neighbors_device(self.h, int(ilist_t.numel()), _ptr(ilist_t), _ptr(first_t),
+                                                   _ptr(neigh_t), int(nall), int(max_numneigh)))
+
+    def compute(self, x, types, eflag=3, vflag=4, grade=False):
+        x = np.ascontiguousarray(x, np.float64)
+        types = np.ascontiguousarray(types, np.int32)
+        nall = x.shape[0]
+        assert nall == self.nall
+        f = np.zeros((nall, 3))
+        eatom = np.zeros(nall)
+        vatom = np.zeros((nall, 6))
+        virial = np.zeros(6)
+        e = C.c_double(0)
+        mg = C.c_double(0)
+        grades = np.zeros(nall) if grade else None
+        cd = np.zeros(self.pot.info.coeff_count) if grade else None
+        self._check(lib().mtp_compute(self.h, _np(x, C.c_double), _np(types, C.c_int), int(eflag), int(vflag),
+                                      int(bool(grade)), _np(f, C.c_double), _np(eatom, C.c_double),
+                                      _np(vatom, C.c_double), C.byref(e), _np(virial, C.c_double),
+                                      _np(grades, C.c_double), C.byref(mg), _np(cd, C.c_double)))
+        out = dict(energy=e.value, eatom=eatom, f=f, virial=virial, vatom=vatom)
+        if grade:
+            out.update(grades=grades, max_grade=mg.value, coeff_ders=cd)
+        return out
+
+    def compute_device(self, x_t, type_t, f_t, eflag=0, vflag=0, grade=False, eatom_t=None, vatom_t=None,
+                       ev_t=None, grades_t=None, maxg_t=None, coeff_t=None, stream=None):
+        st = C.c_void_p(stream) if stream else None
+        self._check(lib().mtp_compute_device(self.h, st, _ptr(x_t), _ptr(type_t), int(eflag), int(vflag),
+                                             int(bool(grade)), _ptr(f_t), _ptr(eatom_t), _ptr(vatom_t),
+                                             _ptr(ev_t), _ptr(grades_t), _ptr(maxg_t), _ptr(coeff_t)))
+
+    def synchronize(self, stream=None):
+        self._check(lib().mtp_synchronize(self.h, C.c_void_p(stream) if stream else None))
+
+    def launch_info(self):
+        a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(lib().mtp_context_launch_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(lds_bytes_per_wave=a.value, waves_per_block=b.value, grid_blocks=c.value,
+                    neighbor_tile=d.value)
+
+    def set_timing(self, on=True):
+        self._check(lib().mtp_context_set_timing(self.h, int(on)))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        self._check(lib().mtp_context_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,572 @@
+// Context (one GPU) and the extern "C" entry points of libmtp_mi355x (include/mtp_mi355x.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mtp_mi355x.h"
+#include "mtp_device.hpp"
+#include "mtp_potential.hpp"
+
+namespace {
+
+struct HipFail {
+  hipError_t e;
+  const char *what;
+};
+#define HIP_CHECK(call)                                   \
+  do {                                                    \
+    hipError_t _e = (call);                               \
+    if (_e != hipSuccess) throw HipFail{_e, #call};       \
+  } while (0)
+
+template <class T> struct DevBuf {
+  T *ptr = nullptr;
+  size_t cap = 0;
+  void reserve(size_t n)
+  {
+    if (n <= cap) return;
+    if (ptr) (void) hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&ptr), std::max<size_t>(n, 1) * sizeof(T)));
+    cap = n;
+  }
+  void upload(const T *src, size_t n, hipStream_t st)
+  {
+    reserve(n);
+    if (n) HIP_CHECK(hipMemcpyAsync(ptr, src, n * sizeof(T), hipMemcpyHostToDevice, st));
+  }
+  void upload(const std::vector<T> &v, hipStream_t st) { upload(v.data(), v.size(), st); }
+  ~DevBuf()
+  {
+    if (ptr) (void) hipFree(ptr);
+  }
+};
+
+void copy_err(const std::string &s, char *err, int errlen)
+{
+  if (err && errlen > 0) std::snprintf(err, (size_t) errlen, "%s", s.c_str());
+}
+
+}   // namespace
+
+struct mtp_context {
+  const mtp_potential *pot = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  int variant = MTP_VARIANT_AUTO;
+  int num_cus = 256;
+  // potential tables
+  DevBuf<double> d_radial, d_seed_val, d_lin, d_species, d_inv_active;
+  DevBuf<int> d_basic_pack, d_slot_of, d_level_off, d_seed_idx, d_map;
+  DevBuf<int4> d_rows;
+  // neighbour list
+  DevBuf<int> d_ilist, d_first, d_neigh;
+  const int *ilist = nullptr, *first = nullptr, *neigh = nullptr;   // active (owned or caller's)
+  int inum = 0, nall = 0, max_numneigh = 0;
+  bool have_list = false;
+  // host-path staging
+  DevBuf<double> d_x, d_f, d_eatom, d_vatom, d_grades, d_coeff;
+  DevBuf<int> d_type;
+  std::vector<double> h_tmp;
+  // workspaces
+  DevBuf<double> d_ev_slots, d_ev, d_maxg;
+  DevBuf<int> d_err;
+  // launch geometry
+  int NT = 32, wpb = 4, grid = 0, wave_doubles = 0;
+  size_t lds_bytes = 0;
+  // timing
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+
+  MtpDevParams base{};
+
+  void plan();
+};
+
+// Choose the neighbour tile and the workgroup shape from the LDS budget (160 KiB / CU).
+void mtp_context::plan()
+{
+  const mtp_potential &p = *pot;
+  const int A = p.alpha_moment_count, P = p.max_alpha_index_basic;
+  const int stride = 2 * p.slot_count + 6 * P;
+  const int cap = std::max(64, (max_numneigh + 63) / 64 * 64);
+  auto wave_bytes = [&](int nt) {
+    size_t dbl = (size_t) 2 * A + (size_t) nt * stride + 5 * (size_t) nt + 64;
+    size_t ints = (size_t) 2 * nt + cap;
+    return (dbl * 8 + ints * 4 + 15) / 16 * 16;
+  };
+  // prefer one tile for typical neighbour counts (32) but drop to 16 when that would
+  // leave fewer than 6 wavefronts per CU
+  NT = 32;
+  if (160 * 1024 / wave_bytes(32) < 6 && 160 * 1024 / wave_bytes(16) > 160 * 1024 / wave_bytes(32)) NT = 16;
+  size_t wb = wave_bytes(NT);
+  if (wb > 160 * 1024) throw HipFail{hipErrorInvalidValue, "potential + neighbour list exceed one CU's LDS"};
+  wave_doubles = (int) (wb / 8);
+  int max_waves_per_cu = (int) std::min<size_t>(160 * 1024 / wb, 16);   // <= 16: VGPR-bound anyway
+  // LARGE: 4 wavefronts (4 atoms) per workgroup; SMALL: 1 wavefront per workgroup so few
+  // atoms still spread over all CUs
+  int want = (variant == MTP_VARIANT_SMALL) ? 1 : 4;
+  if (variant == MTP_VARIANT_AUTO && inum < num_cus * 8) want = 1;
+  wpb = std::max(1, std::min(want, max_waves_per_cu));
+  lds_bytes = wb * wpb;
+  const int blocks_per_cu = std::max(1, max_waves_per_cu / wpb);
+  const int need = (inum + wpb - 1) / wpb;
+  grid = std::max(1, std::min(need, num_cus * blocks_per_cu * 4));
+  base.NT = NT;
+  base.stride = stride;
+  base.cj_cap = cap;
+  base.wave_doubles = wave_doubles;
+}
+
+extern "C" {
+
+int mtp_potential_load(const char *path, int want_selection, mtp_potential **out, char *err, int errlen)
+{
+  if (!path || !out) return MTP_ERR_ARG;
+  *out = nullptr;
+  mtp_potential *p = new (std::nothrow) mtp_potential();
+  if (!p) return MTP_ERR_ARG;
+  std::string msg;
+  int rc = mtp_parse_file(path, want_selection != 0, *p, msg);
+  if (rc != MTP_OK) {
+    copy_err(msg, err, errlen);
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return MTP_OK;
+}
+
+void mtp_potential_free(mtp_potential *pot) { delete pot; }
+
+int mtp_potential_get_info(const mtp_potential *p, mtp_potential_info *info)
+{
+  if (!p || !info) return MTP_ERR_ARG;
+  info->species_count = p->species_count;
+  info->radial_basis_size = p->radial_basis_size;
+  info->radial_func_count = p->radial_func_count;
+  info->alpha_moment_count = p->alpha_moment_count;
+  info->alpha_index_basic_count = p->alpha_index_basic_count;
+  info->alpha_index_times_count = p->alpha_index_times_count;
+  info->alpha_scalar_count = p->alpha_scalar_count;
+  info->max_alpha_index_basic = p->max_alpha_index_basic;
+  info->coeff_count = p->coeff_count;
+  info->has_selection = p->has_selection;
+  info->configuration_mode = p->configuration_mode;
+  info->product_levels = (int) p->level_offset.size() - 1;
+  info->scaling = p->scaling;
+  info->min_cutoff = p->min_cutoff;
+  info->max_cutoff = p->max_cutoff;
+  return MTP_OK;
+}
+
+int mtp_potential_get_tables(const mtp_potential *p, int32_t *aib, int32_t *ait, int32_t *map, double *rc,
+                             double *sc, double *mc, double *inv)
+{
+  if (!p) return MTP_ERR_ARG;
+  auto cp = [](auto *dst, const auto &v) {
+    if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0]));
+  };
+  cp(aib, p->alpha_index_basic);
+  cp(ait, p->alpha_index_times);
+  cp(map, p->alpha_moment_mapping);
+  cp(rc, p->radial_basis_coeffs);
+  cp(sc, p->species_coeffs);
+  cp(mc, p->linear_coeffs);
+  if (inv) {
+    if (!p->has_selection) return MTP_ERR_STATE;
+    cp(inv, p->inverse_active_set);
+  }
+  return MTP_OK;
+}
+
+int mtp_cfg_grade(const mtp_potential *p, const double *c, double *grade)
+{
+  if (!p || !c || !grade) return MTP_ERR_ARG;
+  if (!p->has_selection) return MTP_ERR_STATE;
+  const int C = p->coeff_count;
+  double mx = 0.0;
+  for (int i = 0; i < C; i++) {
+    const double *row = &p->inverse_active_set[(size_t) i * C];
+    double g = 0.0;
+    for (int j = 0; j < C; j++) g += c[j] * row[j];
+    mx = std::max(mx, g < 0 ? -g : g);
+  }
+  *grade = mx;
+  return MTP_OK;
+}
+
+int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **out, char *err, int errlen)
+{
+  if (!pot || !out) return MTP_ERR_ARG;
+  *out = nullptr;
+  mtp_context *c = nullptr;
+  try {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      copy_err("no HIP device is visible: libmtp_mi355x has no CPU fallback", err, errlen);
+      return MTP_ERR_DEVICE;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+      copy_err("device id out of range", err, errlen);
+      return MTP_ERR_ARG;
+    }
+    HIP_CHECK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      copy_err(std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only", err,
+               errlen);
+      return MTP_ERR_DEVICE;
+    }
+    c = new mtp_context();
+    c->pot = pot;
+    c->device = device_id;
+    c->num_cus = prop.multiProcessorCount;
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    hipStream_t st = c->stream;
+    c->d_radial.upload(pot->radial_basis_coeffs, st);
+    c->d_basic_pack.upload(pot->basic_pack, st);
+    c->d_slot_of.upload(pot->slot_of, st);
+    static_assert(sizeof(MtpRow) == sizeof(int4), "row layout");
+    c->d_rows.upload(reinterpret_cast<const int4 *>(pot->rows_by_level.data()), pot->rows_by_level.size(), st);
+    c->d_level_off.upload(pot->level_offset, st);
+    c->d_seed_idx.upload(pot->seed_idx, st);
+    c->d_seed_val.upload(pot->seed_val, st);
+    c->d_map.upload(pot->alpha_moment_mapping, st);
+    c->d_lin.upload(pot->linear_coeffs, st);
+    c->d_species.upload(pot->species_coeffs, st);
+    if (pot->has_selection) c->d_inv_active.upload(pot->inverse_active_set, st);
+    c->d_ev_slots.reserve((size_t) MTP_EV_SLOTS * 8);
+    HIP_CHECK(hipMemsetAsync(c->d_ev_slots.ptr, 0, (size_t) MTP_EV_SLOTS * 8 * sizeof(double), st));
+    c->d_ev.reserve(8);
+    c->d_maxg.reserve(1);
+    c->d_err.reserve(1);
+    HIP_CHECK(hipMemsetAsync(c->d_err.ptr, 0, sizeof(int), st));
+    HIP_CHECK(hipStreamSynchronize(st));
+
+    MtpDevParams &b = c->base;
+    b.Sp = pot->species_count;
+    b.R = pot->radial_basis_size;
+    b.Mu = pot->radial_func_count;
+    b.P = pot->max_alpha_index_basic;
+    b.A = pot->alpha_moment_count;
+    b.B = pot->alpha_index_basic_count;
+    b.T = pot->alpha_index_times_count;
+    b.S = pot->alpha_scalar_count;
+    b.C = pot->coeff_count;
+    b.nslot = pot->slot_count;
+    b.nlevels = (int) pot->level_offset.size() - 1;
+    b.nseed = (int) pot->seed_idx.size();
+    b.rmin = pot->min_cutoff;
+    b.rmax = pot->max_cutoff;
+    b.scaling = pot->scaling;
+    b.cutsq = pot->max_cutoff * pot->max_cutoff;   // pair_mtp.cpp:449,456
+    b.radial_coeffs = c->d_radial.ptr;
+    b.basic_pack = c->d_basic_pack.ptr;
+    b.slot_of = c->d_slot_of.ptr;
+    b.rows = c->d_rows.ptr;
+    b.level_off = c->d_level_off.ptr;
+    b.seed_idx = c->d_seed_idx.ptr;
+    b.seed_val = c->d_seed_val.ptr;
+    b.map = c->d_map.ptr;
+    b.lin = c->d_lin.ptr;
+    b.species_coeffs = c->d_species.ptr;
+    b.inv_active = pot->has_selection ? c->d_inv_active.ptr : nullptr;
+    b.ev_slots = c->d_ev_slots.ptr;
+    b.err_flag = c->d_err.ptr;
+    if ((pot->alpha_index_basic_count + 63) / 64 > 8) {
+      copy_err("alpha_index_basic_count above 512 is not supported by this build", err, errlen);
+      delete c;
+      return MTP_ERR_LIMIT;
+    }
+  } catch (const HipFail &f) {
+    copy_err(std::string(f.what) + ": " + hipGetErrorString(f.e), err, errlen);
+    delete c;
+    return MTP_ERR_DEVICE;
+  }
+  *out = c;
+  return MTP_OK;
+}
+
+void mtp_context_destroy(mtp_context *c)
+{
+  if (!c) return;
+  (void) hipSetDevice(c->device);
+  if (c->ev0) (void) hipEventDestroy(c->ev0);
+  if (c->ev1) (void) hipEventDestroy(c->ev1);
+  if (c->stream) {
+    (void) hipStreamSynchronize(c->stream);
+    (void) hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+const char *mtp_last_error(const mtp_context *c) { return c ? c->last_error.c_str() : "null context"; }
+
+int mtp_context_set_variant(mtp_context *c, int variant)
+{
+  if (!c || variant < MTP_VARIANT_AUTO || variant > MTP_VARIANT_SMALL) return MTP_ERR_ARG;
+  c->variant = variant;
+  if (c->have_list) {
+    try {
+      c->plan();
+    } catch (const HipFail &f) {
+      c->last_error = f.what;
+      return MTP_ERR_LIMIT;
+    }
+  }
+  return MTP_OK;
+}
+
+static int finish_list(mtp_context *c, int inum, int nall, int max_numneigh)
+{
+  c->inum = inum;
+  c->nall = nall;
+  c->max_numneigh = max_numneigh;
+  c->have_list = true;
+  try {
+    c->plan();
+  } catch (const HipFail &f) {
+    c->last_error = f.what;
+    c->have_list = false;
+    return MTP_ERR_LIMIT;
+  }
+  return MTP_OK;
+}
+
+int mtp_set_neighbors_csr(mtp_context *c, int inum, const int *ilist, const int *first, const int *neigh,
+                          int nall)
+{
+  if (!c || inum < 0 || nall < inum || (inum > 0 && (!ilist || !first))) return MTP_ERR_ARG;
+  try {
+    HIP_CHECK(hipSetDevice(c->device));
+    int mx = 0;
+    for (int ii = 0; ii < inum; ii++) mx = std::max(mx, first[ii + 1] - first[ii]);
+    const int total = inum > 0 ? first[inum] : 0;
+    if (total > 0 && !neigh) return MTP_ERR_ARG;
+    c->d_ilist.upload(ilist, (size_t) inum, c->stream);
+    std::vector<int> z(1, 0);
+    c->d_first.upload(inum > 0 ? first : z.data(), (size_t) inum + 1, c->stream);
+    c->d_neigh.upload(neigh, (size_t) total, c->stream);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->ilist = c->d_ilist.ptr;
+    c->first = c->d_first.ptr;
+    c->neigh = c->d_neigh.ptr;
+    return finish_list(c, inum, nall, mx);
+  } catch (const HipFail &f) {
+    c->last_error = std::string(f.what) + ": " + hipGetErrorString(f.e);
+    return MTP_ERR_DEVICE;
+  }
+}
+
+int mtp_set_neighbors(mtp_context *c, int inum, const int *ilist, const int *numneigh,
+                      const int *const *firstneigh, int nall)
+{
+  if (!c || inum < 0 || (inum > 0 && (!ilist || !numneigh || !firstneigh))) return MTP_ERR_ARG;
+  std::vector<int> first((size_t) inum + 1, 0);
+  for (int ii = 0; ii < inum; ii++) first[ii + 1] = first[ii] + numneigh[ilist[ii]];
+  std::vector<int> neigh((size_t) first[inum]);
+  for (int ii = 0; ii < inum; ii++) {
+    const int i = ilist[ii];
+    std::copy(firstneigh[i], firstneigh[i] + numneigh[i], neigh.begin() + first[ii]);
+  }
+  return mtp_set_neighbors_csr(c, inum, ilist, first.data(), neigh.data(), nall);
+}
+
+int mtp_set_neighbors_device(mtp_context *c, int inum, const int *d_ilist, const int *d_first,
+                             const int *d_neigh, int nall, int max_numneigh)
+{
+  if (!c || inum < 0 || nall < inum || max_numneigh < 0 || (inum > 0 && (!d_ilist || !d_first))) return MTP_ERR_ARG;
+  c->ilist = d_ilist;
+  c->first = d_first;
+  c->neigh = d_neigh;
+  return finish_list(c, inum, nall, max_numneigh);
+}
+
+int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const int *d_type, int eflag, int vflag,
+                       int grade_flag, double *d_f, double *d_eatom, double *d_vatom, double *d_ev,
+                       double *d_grades, double *d_max_grade, double *d_coeff_ders)
+{
+  if (!c) return MTP_ERR_ARG;
+  if (!c->have_list) {
+    c->last_error = "mtp_compute before mtp_set_neighbors";
+    return MTP_ERR_STATE;
+  }
+  if (!d_x || !d_type || !d_f) return MTP_ERR_ARG;
+  if (grade_flag && !c->pot->has_selection) {
+    c->last_error = "extrapolation grades requested but the potential has no #MVS_v1.1 selection state";
+    return MTP_ERR_STATE;
+  }
+  if (grade_flag) {
+    c->last_error = "extrapolation grades are not implemented in this build";
+    return MTP_ERR_STATE;
+  }
+  if (((eflag & MTP_ENERGY_GLOBAL) || vflag) && !d_ev) return MTP_ERR_ARG;
+  if (c->inum == 0) return MTP_OK;
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+  MtpDevParams p = c->base;
+  p.inum = c->inum;
+  p.nall = c->nall;
+  p.ilist = c->ilist;
+  p.first = c->first;
+  p.neigh = c->neigh;
+  p.x = d_x;
+  p.type = d_type;
+  p.f = d_f;
+  p.eatom = d_eatom;
+  p.vatom = d_vatom;
+  p.grades = d_grades;
+  p.max_grade = d_max_grade;
+  p.coeff_ders = d_coeff_ders;
+  p.eflag = eflag;
+  p.vflag = vflag;
+  p.grade_flag = grade_flag;
+  try {
+    if (c->timing) {
+      if (!c->ev0) {
+        HIP_CHECK(hipEventCreate(&c->ev0));
+        HIP_CHECK(hipEventCreate(&c->ev1));
+      }
+      HIP_CHECK(hipEventRecord(c->ev0, st));
+    }
+    HIP_CHECK(mtp_launch_wave_kernel(p, c->grid, c->wpb, c->lds_bytes, st));
+    if (c->timing) {
+      HIP_CHECK(hipEventRecord(c->ev1, st));
+      c->timed = true;
+    }
+    if ((eflag & MTP_ENERGY_GLOBAL) || vflag) HIP_CHECK(mtp_launch_ev_finish(c->d_ev_slots.ptr, d_ev, st));
+  } catch (const HipFail &f) {
+    c->last_error = std::string(f.what) + ": " + hipGetErrorString(f.e);
+    return MTP_ERR_DEVICE;
+  }
+  return MTP_OK;
+}
+
+int mtp_synchronize(mtp_context *c, void *stream)
+{
+  if (!c) return MTP_ERR_ARG;
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+  int flag = 0;
+  hipError_t e = hipMemcpyAsync(&flag, c->d_err.ptr, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    c->last_error = std::string("synchronize: ") + hipGetErrorString(e);
+    return MTP_ERR_DEVICE;
+  }
+  if (flag) {
+    (void) hipMemsetAsync(c->d_err.ptr, 0, sizeof(int), st);
+    (void) hipStreamSynchronize(st);
+    c->last_error = "Too few species count in the MTP potential!";   // pair_mtp.cpp:92-93
+    return MTP_ERR_SPECIES;
+  }
+  return MTP_OK;
+}
+
+int mtp_compute(mtp_context *c, const double *x, const int *type, int eflag, int vflag, int grade_flag,
+                double *f, double *eatom, double *vatom, double *energy, double *virial, double *grades,
+                double *max_grade, double *coeff_ders)
+{
+  if (!c || !x || !type || !f) return MTP_ERR_ARG;
+  if (!c->have_list) {
+    c->last_error = "mtp_compute before mtp_set_neighbors";
+    return MTP_ERR_STATE;
+  }
+  const size_t nall = (size_t) c->nall;
+  try {
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    c->d_x.upload(x, 3 * nall, st);
+    c->d_type.upload(type, nall, st);
+    c->d_f.reserve(3 * nall);
+    HIP_CHECK(hipMemsetAsync(c->d_f.ptr, 0, 3 * nall * sizeof(double), st));
+    const bool want_ea = (eflag & MTP_ENERGY_ATOM) && eatom;
+    const bool want_va = (vflag & MTP_VIRIAL_ATOM) && vatom;
+    if (want_ea) c->d_eatom.upload(eatom, nall, st);   // keeps entries of atoms outside ilist
+    if (want_va) {
+      c->d_vatom.reserve(6 * nall);
+      HIP_CHECK(hipMemsetAsync(c->d_vatom.ptr, 0, 6 * nall * sizeof(double), st));
+    }
+    HIP_CHECK(hipMemsetAsync(c->d_ev.ptr, 0, 8 * sizeof(double), st));
+    if (grade_flag) {
+      c->d_grades.reserve(nall);
+      c->d_coeff.reserve((size_t) c->pot->coeff_count);
+      HIP_CHECK(hipMemsetAsync(c->d_grades.ptr, 0, nall * sizeof(double), st));
+      HIP_CHECK(hipMemsetAsync(c->d_coeff.ptr, 0, (size_t) c->pot->coeff_count * sizeof(double), st));
+      HIP_CHECK(hipMemsetAsync(c->d_maxg.ptr, 0, sizeof(double), st));
+    }
+    int rc = mtp_compute_device(c, st, c->d_x.ptr, c->d_type.ptr, eflag, vflag, grade_flag, c->d_f.ptr,
+                                want_ea ? c->d_eatom.ptr : nullptr, want_va ? c->d_vatom.ptr : nullptr,
+                                c->d_ev.ptr, grade_flag ? c->d_grades.ptr : nullptr,
+                                grade_flag ? c->d_maxg.ptr : nullptr, grade_flag ? c->d_coeff.ptr : nullptr);
+    if (rc != MTP_OK) return rc;
+    c->h_tmp.resize(std::max<size_t>(6 * nall, 16));
+    HIP_CHECK(hipMemcpyAsync(c->h_tmp.data(), c->d_f.ptr, 3 * nall * sizeof(double), hipMemcpyDeviceToHost, st));
+    rc = mtp_synchronize(c, st);
+    if (rc != MTP_OK) return rc;
+    for (size_t q = 0; q < 3 * nall; q++) f[q] += c->h_tmp[q];
+    if (want_ea) HIP_CHECK(hipMemcpy(eatom, c->d_eatom.ptr, nall * sizeof(double), hipMemcpyDeviceToHost));
+    if (want_va) {
+      HIP_CHECK(hipMemcpy(c->h_tmp.data(), c->d_vatom.ptr, 6 * nall * sizeof(double), hipMemcpyDeviceToHost));
+      for (size_t q = 0; q < 6 * nall; q++) vatom[q] += c->h_tmp[q];
+    }
+    double ev[8];
+    HIP_CHECK(hipMemcpy(ev, c->d_ev.ptr, 8 * sizeof(double), hipMemcpyDeviceToHost));
+    if ((eflag & MTP_ENERGY_GLOBAL) && energy) *energy += ev[0];
+    if (vflag && virial)
+      for (int q = 0; q < 6; q++) virial[q] += ev[1 + q];
+    if (grade_flag) {
+      if (grades) HIP_CHECK(hipMemcpy(grades, c->d_grades.ptr, nall * sizeof(double), hipMemcpyDeviceToHost));
+      if (max_grade) HIP_CHECK(hipMemcpy(max_grade, c->d_maxg.ptr, sizeof(double), hipMemcpyDeviceToHost));
+      if (coeff_ders)
+        HIP_CHECK(hipMemcpy(coeff_ders, c->d_coeff.ptr, (size_t) c->pot->coeff_count * sizeof(double),
+                            hipMemcpyDeviceToHost));
+    }
+  } catch (const HipFail &fl) {
+    c->last_error = std::string(fl.what) + ": " + hipGetErrorString(fl.e);
+    return MTP_ERR_DEVICE;
+  }
+  return MTP_OK;
+}
+
+int mtp_context_launch_info(const mtp_context *c, int32_t *lds_bytes_per_wave, int32_t *waves_per_block,
+                            int32_t *grid_blocks, int32_t *neighbor_tile)
+{
+  if (!c || !c->have_list) return MTP_ERR_STATE;
+  if (lds_bytes_per_wave) *lds_bytes_per_wave = c->wave_doubles * 8;
+  if (waves_per_block) *waves_per_block = c->wpb;
+  if (grid_blocks) *grid_blocks = c->grid;
+  if (neighbor_tile) *neighbor_tile = c->NT;
+  return MTP_OK;
+}
+
+int mtp_context_set_timing(mtp_context *c, int enable)
+{
+  if (!c) return MTP_ERR_ARG;
+  c->timing = enable != 0;
+  c->timed = false;
+  return MTP_OK;
+}
+
+int mtp_context_last_kernel_ms(mtp_context *c, float *ms)
+{
+  if (!c || !ms) return MTP_ERR_ARG;
+  if (!c->timed) return MTP_ERR_STATE;
+  hipError_t e = hipEventSynchronize(c->ev1);
+  if (e == hipSuccess) e = hipEventElapsedTime(ms, c->ev0, c->ev1);
+  if (e != hipSuccess) {
+    c->last_error = std::string("event timing: ") + hipGetErrorString(e);
+    return MTP_ERR_DEVICE;
+  }
+  return MTP_OK;
+}
+
+}   // extern "C"

@@ -1,0 +1,406 @@
+// MLIP-3 potential file reader and native schedule builder (host only).
+//
+// Grammar and error behaviour follow PairMTP::read_file
+// (/root/reference/LAMMPS/ML-MTP/pair_mtp.cpp:335-570), RadialMTPBasis::ReadBasisProperties
+// (mtp_radial_basis.cpp:59-102) and PairMTPExtrapolation::read_file
+// (pair_mtp_extrapolation.cpp:528-612); SURVEY.md App. A is the condensed grammar.
+#include "mtp_potential.hpp"
+
+#include "../../include/mtp_mi355x.h"
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+namespace {
+
+struct ParseError {
+  int code;
+  std::string msg;
+};
+
+// LAMMPS TextFileReader semantics the reference depends on: fgets into a buffer whose
+// size the caller may change (pair_mtp.cpp:489-492, 525-528), '#' starts a comment when
+// ignore_comments is set, lines without words are skipped.
+class LineReader {
+ public:
+  explicit LineReader(FILE *fp) : fp_(fp), buf_(1024) {}
+  bool ignore_comments = true;
+  void set_bufsize(size_t n) { buf_.assign(std::max<size_t>(n, 2), '\0'); }
+  // returns false at end of file
+  bool next(std::string &out)
+  {
+    while (fgets(buf_.data(), (int) buf_.size(), fp_)) {
+      out.assign(buf_.data());
+      if (ignore_comments) {
+        auto p = out.find('#');
+        if (p != std::string::npos) out.erase(p);
+      }
+      if (out.find_first_not_of(" \t\r\n\f") != std::string::npos) return true;
+    }
+    return false;
+  }
+
+ private:
+  FILE *fp_;
+  std::vector<char> buf_;
+};
+
+// ValueTokenizer: split on a separator set; typed getters fail loudly.
+class Tokens {
+ public:
+  Tokens() = default;
+  Tokens(const std::string &line, const char *seps) : s_(line), seps_(seps) {}
+  bool next(std::string &w)
+  {
+    size_t b = s_.find_first_not_of(seps_, pos_);
+    if (b == std::string::npos) return false;
+    size_t e = s_.find_first_of(seps_, b);
+    if (e == std::string::npos) e = s_.size();
+    w = s_.substr(b, e - b);
+    pos_ = e;
+    return true;
+  }
+  std::string word()
+  {
+    std::string w;
+    if (!next(w)) throw ParseError{MTP_ERR_PARSE, "Not enough tokens"};
+    return w;
+  }
+  int integer()
+  {
+    std::string w = word();
+    char *e = nullptr;
+    errno = 0;
+    long v = std::strtol(w.c_str(), &e, 10);
+    if (*e || errno) throw ParseError{MTP_ERR_PARSE, "Not a valid integer number: '" + w + "'"};
+    return (int) v;
+  }
+  double real()
+  {
+    std::string w = word();
+    char *e = nullptr;
+    double v = std::strtod(w.c_str(), &e);
+    if (*e) throw ParseError{MTP_ERR_PARSE, "Not a valid floating-point number: '" + w + "'"};
+    return v;
+  }
+
+ private:
+  std::string s_;
+  std::string seps_;
+  size_t pos_ = 0;
+};
+
+const char *kSeps = " \t\r\n\f=, ";
+const char *kSepsDash = " \t\r\n\f=, -";
+const char *kSepsBrace = " \t\r\n\f=, {},";
+
+struct Cursor {
+  LineReader &rd;
+  std::string line, key;
+  Tokens tok;
+  void advance(const char *seps)
+  {
+    if (!rd.next(line)) throw ParseError{MTP_ERR_EOF, "Unexpected end of MTP file."};
+    tok = Tokens(line, seps);
+    if (!tok.next(key)) key.clear();
+  }
+  void expect(const char *kw, const char *msg)
+  {
+    if (key != kw) throw ParseError{MTP_ERR_PARSE, msg};
+  }
+};
+
+void parse_text(FILE *fp, bool want_selection, mtp_potential &p)
+{
+  LineReader rd(fp);
+  Cursor c{rd, {}, {}, {}};
+
+  c.advance(kSeps);
+  if (c.key != "MTP") throw ParseError{MTP_ERR_FORMAT, "Only MTP potential files are accepted."};
+  {
+    std::string ver;
+    if (!rd.next(ver) || ver != "version = 1.1.0\n")   // exact, newline included (:357)
+      throw ParseError{MTP_ERR_FORMAT, "MTP file must have version \"1.1.0\""};
+  }
+  c.advance(kSeps);
+  if (c.key == "potential_name") {
+    std::string w;
+    p.potential_name = c.tok.next(w) ? w : "";
+    c.advance(kSeps);
+  }
+  p.scaling = 1.0;
+  if (c.key == "scaling") {
+    p.scaling = c.tok.real();
+    c.advance(kSeps);
+  }
+  c.expect("species_count", "Error reading MTP file. Species count not found.");
+  p.species_count = c.tok.integer();
+  if (p.species_count < 1) throw ParseError{MTP_ERR_PARSE, "species_count must be positive"};
+
+  c.advance(kSeps);
+  if (c.key == "potential_tag") {
+    std::string w;
+    p.potential_tag = c.tok.next(w) ? w : "";
+    c.advance(kSeps);
+  }
+  c.expect("radial_basis_type", "Error reading MTP file. No radial basis set type is specified.");
+  {
+    std::string ty = c.tok.word();
+    if (ty != "RBChebyshev")
+      throw ParseError{MTP_ERR_UNSUPPORTED,
+                       "Error reading MTP file. The specified radial basis set type, " + ty + ", was not found.."};
+  }
+  // radial basis block (mtp_radial_basis.cpp:59-102)
+  c.advance(kSeps);
+  if (c.key == "scaling") {   // parsed, then superseded by the top-level value (pair_mtp.cpp:416)
+    (void) c.tok.real();
+    c.advance(kSeps);
+  }
+  if (c.key != "min_val" && c.key != "min_dist")
+    throw ParseError{MTP_ERR_PARSE, "Error in reading MTP file. Cannot read lower cutoff."};
+  p.min_cutoff = c.tok.real();
+  c.advance(kSeps);
+  if (c.key != "max_val" && c.key != "max_dist")
+    throw ParseError{MTP_ERR_PARSE, "Error in reading MTP file. Cannot read upper cutoff."};
+  p.max_cutoff = c.tok.real();
+  c.advance(kSeps);
+  c.expect("radial_basis_size", "Error in reading MTP file. Cannot read radial basis set size.");
+  p.radial_basis_size = c.tok.integer();
+
+  c.advance(kSeps);
+  c.expect("radial_funcs_count", "Error in reading MTP file. Cannot read radial function count.");
+  p.radial_func_count = c.tok.integer();
+  c.advance(kSeps);
+  if (c.key != "radial_coeffs") {
+    if (c.key == "magnetic_basis_type")
+      throw ParseError{MTP_ERR_UNSUPPORTED, "Magnetic basis is currently not supported."};
+    throw ParseError{MTP_ERR_PARSE, "Error in reading MTP file. Cannot read radial coeffs count."};
+  }
+  const int Sp = p.species_count, R = p.radial_basis_size, Mu = p.radial_func_count;
+  if (R < 1 || Mu < 1) throw ParseError{MTP_ERR_PARSE, "radial basis sizes must be positive"};
+  p.radial_basis_coeffs.assign((size_t) Sp * Sp * Mu * R, 0.0);
+  p.setflag.assign((size_t) (Sp + 1) * (Sp + 1), 0);
+  for (int blk = 0; blk < Sp * Sp; blk++) {   // any order, 0-based species (:450-469)
+    if (!rd.next(c.line)) throw ParseError{MTP_ERR_EOF, "Unexpected end of MTP file."};
+    Tokens hdr(c.line, kSepsDash);
+    int t1 = hdr.integer(), t2 = hdr.integer();
+    if (t1 < 0 || t2 < 0 || t1 >= Sp || t2 >= Sp)
+      throw ParseError{MTP_ERR_PARSE, "radial_coeffs block names a species outside species_count"};
+    p.setflag[(size_t) (t1 + 1) * (Sp + 1) + t2 + 1] = 1;
+    double *dst = &p.radial_basis_coeffs[(size_t) (t1 * Sp + t2) * Mu * R];
+    for (int mu = 0; mu < Mu; mu++) {
+      if (!rd.next(c.line)) throw ParseError{MTP_ERR_EOF, "Unexpected end of MTP file."};
+      Tokens row(c.line, kSepsBrace);
+      for (int ri = 0; ri < R; ri++) dst[mu * R + ri] = row.real();
+    }
+  }
+  c.advance(kSeps);
+  c.expect("alpha_moments_count", "Error reading MTP file. Alpha moment count not found.");
+  p.alpha_moment_count = c.tok.integer();
+  c.advance(kSeps);
+  c.expect("alpha_index_basic_count", "Error reading MTP file. Alpha moment count not found.");
+  p.alpha_index_basic_count = c.tok.integer();
+  const int B = p.alpha_index_basic_count;
+  if (B < 1) throw ParseError{MTP_ERR_TABLE, "alpha_index_basic_count must be positive"};
+
+  rd.set_bufsize((size_t) B * 20 + 20);
+  c.advance(kSepsBrace);
+  c.expect("alpha_index_basic", "Error reading MTP file. Alpha index basic not found.");
+  p.alpha_index_basic.resize((size_t) B * 4);
+  int mu_max = 0, rank_max = 0;
+  for (int i = 0; i < B; i++) {
+    int32_t *q = &p.alpha_index_basic[4 * (size_t) i];
+    for (int j = 0; j < 4; j++) q[j] = c.tok.integer();
+    mu_max = std::max(mu_max, (int) q[0]);
+    rank_max = std::max(rank_max, (int) (q[1] + q[2] + q[3]));
+  }
+  if (mu_max != Mu - 1) throw ParseError{MTP_ERR_TABLE, "Wrong number of radial functions specified!"};
+  p.max_alpha_index_basic = rank_max + 1;
+
+  c.advance(kSeps);
+  c.expect("alpha_index_times_count", "Error reading MTP file. Alpha index times count not found.");
+  p.alpha_index_times_count = c.tok.integer();
+  const int T = p.alpha_index_times_count;
+  rd.set_bufsize((size_t) std::max(T, 0) * 32 + 20);
+  c.advance(kSepsBrace);
+  c.expect("alpha_index_times", "Error reading MTP file. Alpha index times not found.");
+  p.alpha_index_times.resize((size_t) std::max(T, 0) * 4);
+  for (size_t i = 0; i < p.alpha_index_times.size(); i++) p.alpha_index_times[i] = c.tok.integer();
+
+  c.advance(kSeps);
+  c.expect("alpha_scalar_moments", "Error reading MTP file. Alpha scalar moment count not found.");
+  p.alpha_scalar_count = c.tok.integer();
+  const int S = p.alpha_scalar_count;
+  c.advance(kSepsBrace);
+  c.expect("alpha_moment_mapping", "Error reading MTP file. Alpha moment mappings not found.");
+  p.alpha_moment_mapping.resize((size_t) S);
+  for (int i = 0; i < S; i++) p.alpha_moment_mapping[i] = c.tok.integer();
+  c.advance(kSepsBrace);
+  c.expect("species_coeffs", "Error reading MTP file. Species coefficients not found.");
+  p.species_coeffs.resize((size_t) Sp);
+  for (int i = 0; i < Sp; i++) p.species_coeffs[i] = c.tok.real();
+  c.advance(kSepsBrace);
+  c.expect("moment_coeffs", "Error reading MTP file. Moment coefficients not found.");
+  p.linear_coeffs.resize((size_t) S);
+  for (int i = 0; i < S; i++) p.linear_coeffs[i] = c.tok.real();
+
+  p.coeff_count = Sp * Sp * Mu * R + Sp + S;
+
+  if (!want_selection) return;
+  // selection state (pair_mtp_extrapolation.cpp:545-612)
+  rd.ignore_comments = false;
+  std::string ln;
+  if (!rd.next(ln))
+    throw ParseError{MTP_ERR_SELECTION,
+                     "No selection state found! Consider training/retraining or disabling extrapolation!"};
+  {
+    Tokens t(ln, kSeps);
+    std::string w;
+    if (!t.next(w) || w != "#MVS_v1.1")
+      throw ParseError{MTP_ERR_SELECTION,
+                       "Error in reading MTP file selection state. Please verify MVS version is #MVS_v1.1!"};
+  }
+  rd.ignore_comments = true;
+  int energy_weight = 0, site_en_weight = 0;
+  static const char *names[5] = {"energy_weight", "force_weight", "stress_weight", "site_en_weight",
+                                 "weight_scaling"};
+  for (int w = 0; w < 5; w++) {
+    c.advance(kSeps);
+    if (c.key != names[w])
+      throw ParseError{MTP_ERR_SELECTION, std::string("Error in reading MTP file, ") + names[w]};
+    if (w == 0) energy_weight = (int) c.tok.real();
+    if (w == 3) site_en_weight = (int) c.tok.real();
+  }
+  if (energy_weight + site_en_weight > 1)
+    throw ParseError{MTP_ERR_MODE,
+                     "Error, the MTP currently only supports configuration mode (energy_weight=1) or "
+                     "neighbourhood mode (site_en_weight=1). Please retrain the MTP with the correct modes!"};
+  p.configuration_mode = (energy_weight == 1);
+  const size_t n = (size_t) p.coeff_count * p.coeff_count;
+  p.active_set.resize(n);
+  p.inverse_active_set.resize(n);
+  fgetc(fp);   // the '#' in front of the raw fp64 block (:607)
+  if (fread(p.active_set.data(), sizeof(double), n, fp) != n ||
+      fread(p.inverse_active_set.data(), sizeof(double), n, fp) != n)
+    throw ParseError{MTP_ERR_IO, "Unexpected end of file while reading the active set"};
+  p.has_selection = true;
+}
+
+}   // namespace
+
+int mtp_parse_file(const char *path, bool want_selection, mtp_potential &pot, std::string &err)
+{
+  FILE *fp = std::fopen(path, "rb");
+  if (!fp) {
+    err = std::string("Cannot open potential file ") + path + ": " + std::strerror(errno);
+    return MTP_ERR_IO;
+  }
+  int rc = MTP_OK;
+  try {
+    parse_text(fp, want_selection, pot);
+  } catch (const ParseError &e) {
+    err = e.msg;
+    rc = e.code;
+  } catch (const std::exception &e) {
+    err = e.what();
+    rc = MTP_ERR_PARSE;
+  }
+  std::fclose(fp);
+  if (rc == MTP_OK) rc = pot.finalize(err);
+  return rc;
+}
+
+// Build the native schedule.  The reference executes the times rows strictly in file
+// order (pair_mtp.cpp:196-201) and in reverse for the adjoint (:221-233).  Rows are
+// assigned to dependency levels so that any two rows in one level commute under that
+// sequential semantics (read-after-write and write-after-read on the moment array are
+// both respected); a level is then executed by all lanes at once.
+int mtp_potential::finalize(std::string &err)
+{
+  const int A = alpha_moment_count, B = alpha_index_basic_count, T = alpha_index_times_count;
+  const int S = alpha_scalar_count, P = max_alpha_index_basic, Mu = radial_func_count;
+  if (A < B) {
+    err = "alpha_moments_count is smaller than alpha_index_basic_count";
+    return MTP_ERR_TABLE;
+  }
+  for (int i = 0; i < B; i++) {
+    const int32_t *q = &alpha_index_basic[4 * (size_t) i];
+    if (q[0] < 0 || q[1] < 0 || q[2] < 0 || q[3] < 0) {
+      err = "negative entry in alpha_index_basic";
+      return MTP_ERR_TABLE;
+    }
+    if (q[1] > 15 || q[2] > 15 || q[3] > 15) {
+      err = "alpha_index_basic exponent above 15 is not supported";
+      return MTP_ERR_LIMIT;
+    }
+  }
+  std::vector<int> wlevel((size_t) A, 0), rlevel((size_t) A, 0);
+  std::vector<int> lvl((size_t) T, 0);
+  int nlev = 0;
+  for (int k = 0; k < T; k++) {
+    const int32_t *q = &alpha_index_times[4 * (size_t) k];
+    for (int j : {0, 1, 3})
+      if (q[j] < 0 || q[j] >= A) {
+        err = "alpha_index_times refers to a moment outside alpha_moments_count";
+        return MTP_ERR_TABLE;
+      }
+    int l = std::max(wlevel[q[0]], wlevel[q[1]]) + 1;   // operands complete
+    l = std::max(l, rlevel[q[3]] + 1);                  // earlier readers of a3 come first
+    lvl[k] = l;
+    wlevel[q[3]] = std::max(wlevel[q[3]], l);
+    rlevel[q[0]] = std::max(rlevel[q[0]], l);
+    rlevel[q[1]] = std::max(rlevel[q[1]], l);
+    nlev = std::max(nlev, l);
+  }
+  level_offset.assign((size_t) nlev + 1, 0);
+  for (int k = 0; k < T; k++) level_offset[lvl[k]]++;        // counts at [1..nlev]
+  for (int l = 1; l <= nlev; l++) level_offset[l] += level_offset[l - 1];
+  // level_offset[l] now = end of level l; shift to starts
+  std::vector<int32_t> start((size_t) nlev + 1, 0);
+  for (int l = 1; l <= nlev; l++) start[l] = level_offset[l - 1];
+  rows_by_level.assign((size_t) T, MtpRow{0, 0, 0, 0});
+  {
+    std::vector<int32_t> cur(start);
+    for (int k = 0; k < T; k++) {
+      const int32_t *q = &alpha_index_times[4 * (size_t) k];
+      rows_by_level[cur[lvl[k]]++] = MtpRow{q[0], q[1], q[2], q[3]};
+    }
+  }
+  // level l (1-based) spans [level_offset[l-1], level_offset[l])
+  for (int i = 0; i < S; i++)
+    if (alpha_moment_mapping[i] < 0 || alpha_moment_mapping[i] >= A) {
+      err = "alpha_moment_mapping refers to a moment outside alpha_moments_count";
+      return MTP_ERR_TABLE;
+    }
+  // adjoint seeds: assignment, so the last scalar mapped to a moment wins (:217-218)
+  {
+    std::vector<int> last((size_t) A, -1);
+    for (int i = 0; i < S; i++) last[alpha_moment_mapping[i]] = i;
+    seed_idx.clear();
+    seed_val.clear();
+    for (int m = 0; m < A; m++)
+      if (last[m] >= 0) {
+        seed_idx.push_back(m);
+        seed_val.push_back(linear_coeffs[last[m]]);
+      }
+  }
+  slot_of.assign((size_t) Mu * P, -1);
+  slot_count = 0;
+  basic_pack.resize((size_t) B);
+  for (int i = 0; i < B; i++) {
+    const int32_t *q = &alpha_index_basic[4 * (size_t) i];
+    int nu = q[1] + q[2] + q[3];
+    int32_t &s = slot_of[(size_t) q[0] * P + nu];
+    if (s < 0) s = slot_count++;
+    if (s > 255) {
+      err = "more than 256 distinct (mu, nu) radial slots";
+      return MTP_ERR_LIMIT;
+    }
+    basic_pack[i] = s | (q[1] << 8) | (q[2] << 12) | (q[3] << 16);
+  }
+  return MTP_OK;
+}

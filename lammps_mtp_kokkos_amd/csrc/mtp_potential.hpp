@@ -1,0 +1,48 @@
+// Host model of one MLIP-3 potential: the state PairMTP keeps after read_file
+// (/root/reference/LAMMPS/ML-MTP/pair_mtp.h:47-83, pair_mtp_extrapolation.h:44-66) plus the
+// native execution schedule derived from it (dependency levels of the times table,
+// radial slots, packed basic descriptors).  Internal to libmtp_mi355x.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+struct MtpRow {
+  int32_t a0, a1, mult, a3;
+};
+
+struct mtp_potential {
+  // --- as read -------------------------------------------------------------------------
+  std::string potential_name, potential_tag;
+  double scaling = 1.0, min_cutoff = 0.0, max_cutoff = 0.0;
+  int species_count = 0, radial_basis_size = 0, radial_func_count = 0;
+  int alpha_moment_count = 0, alpha_index_basic_count = 0, alpha_index_times_count = 0;
+  int alpha_scalar_count = 0, max_alpha_index_basic = 0;
+  std::vector<int32_t> alpha_index_basic;    // [B][4]
+  std::vector<int32_t> alpha_index_times;    // [T][4]
+  std::vector<int32_t> alpha_moment_mapping; // [S]
+  std::vector<double> radial_basis_coeffs;   // [(t1*Sp+t2)*Mu*R + mu*R + ri]
+  std::vector<double> linear_coeffs, species_coeffs;
+  std::vector<int32_t> setflag;              // [(Sp+1)^2], pair_mtp.cpp:455
+  bool has_selection = false, configuration_mode = false;
+  int coeff_count = 0;
+  std::vector<double> active_set, inverse_active_set;   // [C][C]
+
+  // --- native schedule (built by finalize) -------------------------------------------------
+  // times rows stably sorted by dependency level; level_offset[l]..level_offset[l+1]
+  std::vector<MtpRow> rows_by_level;
+  std::vector<int32_t> level_offset;
+  // distinct (mu, nu) pairs used by the basics -> slot; slot_of[mu*P+nu] or -1
+  std::vector<int32_t> slot_of;
+  int slot_count = 0;
+  // per basic: slot | a<<8 | b<<12 | c<<16 (what a lane needs per k)
+  std::vector<int32_t> basic_pack;
+  // adjoint seeds: D[idx] = val (last mapping entry wins, pair_mtp.cpp:217-218)
+  std::vector<int32_t> seed_idx;
+  std::vector<double> seed_val;
+
+  int finalize(std::string &err);
+};
+
+int mtp_parse_file(const char *path, bool want_selection, mtp_potential &pot, std::string &err);

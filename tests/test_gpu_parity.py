@@ -1,0 +1,273 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on identical
+inputs.  Tolerances (fp64): |dF| <= 1e-9 eV/A + 1e-10 |F|max, |dE|/atom <= 1e-10 eV --
+three orders inside the north-star bound of 1e-6 eV/A; the differences come from
+re-association (lane-parallel sums, FMA contraction), nothing else.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from lammps_mtp_kokkos_amd import capi, mtpgen
+from lammps_mtp_kokkos_amd.driver import periodic_system
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+POT = os.path.join(ROOT, "potentials")
+
+
+def _oracle(path, selection=False):
+    from oracle.pyoracle import Oracle
+    return Oracle(path, selection=selection)
+
+
+def _close(got, want, what, atol=1e-9, rtol=1e-10):
+    scale = max(1.0, float(np.abs(want).max())) if np.size(want) else 1.0
+    err = float(np.abs(np.asarray(got) - np.asarray(want)).max()) if np.size(want) else 0.0
+    assert err <= atol + rtol * scale, "%s: max abs err %.3e (scale %.3e)" % (what, err, scale)
+    return err
+
+
+def _compare(path, s, eflag=3, vflag=4, variant=None, selection=False):
+    pot = capi.Potential(path, selection=selection)
+    ctx = capi.Context(pot, 0)
+    if variant is not None:
+        ctx.set_variant(variant)
+    ctx.set_neighbors(s.ilist, s.first, s.neigh, s.nall)
+    got = ctx.compute(s.x, s.types, eflag=eflag, vflag=vflag)
+    want = _oracle(path).compute(s.x, s.types, s.ilist, s.first, s.neigh, eflag=eflag, vflag=vflag)
+    _close(got["f"], want["f"], "forces")
+    n = max(1, len(s.ilist))
+    assert abs(got["energy"] - want["energy"]) / n <= 1e-10 * max(1.0, abs(want["energy"]) / n)
+    _close(got["eatom"], want["eatom"], "eatom", atol=1e-10)
+    _close(got["virial"], want["virial"], "virial", atol=1e-8)
+    _close(got["vatom"], want["vatom"], "vatom")
+    return got, want, ctx
+
+
+def _system(ncell, species=1, a=3.165, list_cutoff=7.0, seed=777):
+    pos, box = mtpgen.bcc_lattice(*ncell, a=a, seed=seed)
+    rng = np.random.default_rng(5)
+    types = rng.integers(1, species + 1, size=len(pos)).astype(np.int32)
+    return periodic_system(pos, box, types, list_cutoff)
+
+
+def _pot(tmp, level, species, name):
+    tab = mtpgen.level8_template() if level == 8 else mtpgen.build_table(level)
+    p = mtpgen.random_potential(tab, species, 4242)
+    path = str(tmp / name)
+    mtpgen.write_mtp(p, path)
+    return path
+
+
+def test_config1_level8_256_atoms():
+    s = _system((4, 4, 8))
+    assert s.nlocal == 256
+    _compare(os.path.join(POT, "W_L8.mtp"), s)
+
+
+def test_level16_432_atoms():
+    _compare(os.path.join(POT, "W_L16.mtp"), _system((6, 6, 6)))
+
+
+def test_level20_two_species():
+    _compare(os.path.join(POT, "WRe_L20.mtp"), _system((3, 3, 3), species=2))
+
+
+@pytest.mark.parametrize("level,species", [(6, 1), (10, 3), (12, 2), (14, 1)])
+def test_other_levels_and_species(tmp_path, level, species):
+    _compare(_pot(tmp_path, level, species, "p.mtp"), _system((3, 3, 3), species=species))
+
+
+def test_many_in_cutoff_neighbours_multi_tile():
+    """compressed lattice: 58 neighbours inside 5 A -> more than one 32-neighbour LDS tile"""
+    s = _system((4, 4, 4), a=2.6, list_cutoff=6.0)
+    incut = []
+    for i in range(s.nlocal):
+        js = s.neigh[s.first[i]:s.first[i + 1]]
+        incut.append(int((((s.x[js] - s.x[i]) ** 2).sum(1) <= 25.0).sum()))
+    assert max(incut) > 32
+    _compare(os.path.join(POT, "W_L16.mtp"), s)
+
+
+def test_ragged_lists_empty_rows_and_subset_ilist():
+    s = _system((3, 3, 3))
+    rng = np.random.default_rng(9)
+    keep = rng.permutation(s.nlocal)[: s.nlocal - 7].astype(np.int32)      # permuted subset
+    rows = []
+    for ii, i in enumerate(keep):
+        r = s.neigh[s.first[i]:s.first[i + 1]].copy()
+        rng.shuffle(r)
+        if ii % 5 == 0:
+            r = r[: len(r) // 3]          # truncated row
+        if ii % 11 == 0:
+            r = r[:0]                     # atom with no neighbours at all
+        r = r | (int(rng.integers(0, 4)) << 30)      # LAMMPS special bits above NEIGHMASK
+        rows.append(r.astype(np.int32))
+    first = np.zeros(len(keep) + 1, np.int32)
+    first[1:] = np.cumsum([len(r) for r in rows])
+    s.ilist, s.first, s.neigh = keep, first, np.concatenate(rows).astype(np.int32)
+    _compare(os.path.join(POT, "W_L16.mtp"), s)
+
+
+def test_empty_ilist():
+    s = _system((2, 2, 2))
+    pot = capi.Potential(os.path.join(POT, "W_L8.mtp"))
+    ctx = capi.Context(pot, 0)
+    ctx.set_neighbors(np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32), s.nall)
+    r = ctx.compute(s.x, s.types)
+    assert r["energy"] == 0 and not r["f"].any()
+
+
+def test_lammps_form_neighbor_list_and_accumulate_semantics():
+    s = _system((3, 3, 3))
+    path = os.path.join(POT, "W_L16.mtp")
+    pot = capi.Potential(path)
+    ctx = capi.Context(pot, 0)
+    numneigh = np.zeros(s.nall, np.int32)
+    rows = [np.zeros(0, np.int32)] * s.nall
+    for ii, i in enumerate(s.ilist):
+        rows[i] = s.neigh[s.first[ii]:s.first[ii + 1]]
+        numneigh[i] = len(rows[i])
+    ctx.set_neighbors_lammps(s.ilist, numneigh, rows, s.nall)
+    a = ctx.compute(s.x, s.types)
+    want = _oracle(path).compute(s.x, s.types, s.ilist, s.first, s.neigh)
+    _close(a["f"], want["f"], "forces")
+    # f/virial/energy accumulate into what the caller passes; eatom is assigned
+    import ctypes as C
+    f = np.full((s.nall, 3), 0.5)
+    e = C.c_double(10.0)
+    vir = np.full(6, 2.0)
+    eatom = np.full(s.nall, -7.0)
+    rc = capi.lib().mtp_compute(ctx.h, s.x.ctypes.data_as(C.POINTER(C.c_double)),
+                                s.types.ctypes.data_as(C.POINTER(C.c_int)), 3, 1, 0,
+                                f.ctypes.data_as(C.POINTER(C.c_double)), eatom.ctypes.data_as(C.POINTER(C.c_double)),
+                                None, C.byref(e), vir.ctypes.data_as(C.POINTER(C.c_double)), None, None, None)
+    assert rc == 0
+    _close(f - 0.5, want["f"], "accumulated forces")
+    assert abs(e.value - 10.0 - want["energy"]) < 1e-8
+    _close(vir - 2.0, want["virial"], "virial", atol=1e-8)
+    _close(eatom[: s.nlocal], want["eatom"][: s.nlocal], "eatom")
+    assert (eatom[s.nlocal:] == -7.0).all()          # ghosts untouched (pair_mtp.cpp:210)
+
+
+def test_flags_off_leave_outputs_untouched():
+    s = _system((3, 3, 3))
+    path = os.path.join(POT, "W_L8.mtp")
+    pot = capi.Potential(path)
+    ctx = capi.Context(pot, 0)
+    ctx.set_neighbors(s.ilist, s.first, s.neigh, s.nall)
+    r = ctx.compute(s.x, s.types, eflag=0, vflag=0)
+    want = _oracle(path).compute(s.x, s.types, s.ilist, s.first, s.neigh, eflag=0, vflag=0)
+    _close(r["f"], want["f"], "forces")
+    assert r["energy"] == 0 and not r["eatom"].any() and not r["virial"].any() and not r["vatom"].any()
+    r = ctx.compute(s.x, s.types, eflag=1, vflag=2)          # global only
+    want = _oracle(path).compute(s.x, s.types, s.ilist, s.first, s.neigh, eflag=1, vflag=2)
+    assert abs(r["energy"] - want["energy"]) < 1e-9
+    _close(r["virial"], want["virial"], "virial", atol=1e-8)
+    assert not r["eatom"].any() and not r["vatom"].any()
+
+
+def test_species_outside_potential_is_reported():
+    s = _system((3, 3, 3))
+    pot = capi.Potential(os.path.join(POT, "W_L8.mtp"))
+    ctx = capi.Context(pot, 0)
+    ctx.set_neighbors(s.ilist, s.first, s.neigh, s.nall)
+    t = s.types.copy()
+    t[5] = 2
+    with pytest.raises(capi.MtpError, match="Too few species") as ei:
+        ctx.compute(s.x, t)
+    assert ei.value.code == -22
+    ctx.compute(s.x, s.types)                      # the context stays usable
+
+
+def test_compute_before_neighbors_is_an_error():
+    pot = capi.Potential(os.path.join(POT, "W_L8.mtp"))
+    ctx = capi.Context(pot, 0)
+    with pytest.raises(capi.MtpError) as ei:
+        ctx.nall = 1
+        ctx.compute(np.zeros((1, 3)), np.ones(1, np.int32))
+    assert ei.value.code == -23
+
+
+def test_variants_agree():
+    s = _system((4, 4, 4))
+    path = os.path.join(POT, "W_L16.mtp")
+    a, _, ca = _compare(path, s, variant=capi.VARIANT_LARGE)
+    b, _, cb = _compare(path, s, variant=capi.VARIANT_SMALL)
+    assert ca.launch_info()["waves_per_block"] != cb.launch_info()["waves_per_block"]
+    _close(a["f"], b["f"], "variant forces", atol=1e-10)
+
+
+def test_device_pointer_path_matches_host_path():
+    import torch
+    s = _system((4, 4, 4))
+    path = os.path.join(POT, "W_L16.mtp")
+    pot = capi.Potential(path)
+    ctx = capi.Context(pot, 0)
+    dev = torch.device("cuda:0")
+    il = torch.from_numpy(s.ilist).to(dev)
+    fi = torch.from_numpy(s.first).to(dev)
+    ne = torch.from_numpy(s.neigh).to(dev)
+    ctx.set_neighbors_device(il, fi, ne, s.nall, int(np.diff(s.first).max()))
+    x = torch.from_numpy(s.x).to(dev)
+    ty = torch.from_numpy(s.types).to(dev)
+    f = torch.zeros((s.nall, 3), dtype=torch.float64, device=dev)
+    ea = torch.zeros(s.nall, dtype=torch.float64, device=dev)
+    va = torch.zeros((s.nall, 6), dtype=torch.float64, device=dev)
+    ev = torch.zeros(8, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):                                   # forces accumulate over calls
+        ctx.compute_device(x, ty, f, eflag=3, vflag=4, eatom_t=ea, vatom_t=va, ev_t=ev, stream=st)
+    ctx.synchronize(st)
+    want = _oracle(path).compute(s.x, s.types, s.ilist, s.first, s.neigh)
+    _close(f.cpu().numpy() / 2, want["f"], "device forces")
+    _close(ev.cpu().numpy()[0] / 2, want["energy"], "device energy", atol=1e-8)
+    _close(ev.cpu().numpy()[1:7] / 2, want["virial"], "device virial", atol=1e-8)
+    _close(ea.cpu().numpy(), want["eatom"], "device eatom")
+
+
+def test_golden_fixtures():
+    gdir = os.path.join(ROOT, "tests", "golden")
+    names = sorted(f for f in os.listdir(gdir) if f.endswith(".npz"))
+    assert names
+    for n in names:
+        g = np.load(os.path.join(gdir, n))
+        path = os.path.join(POT, str(g["potential"]))
+        pot = capi.Potential(path)
+        ctx = capi.Context(pot, 0)
+        ctx.set_neighbors(g["ilist"], g["first"], g["neigh"], len(g["x"]))
+        r = ctx.compute(g["x"], g["types"])
+        _close(r["f"], g["f"], n + " forces")
+        _close(r["eatom"], g["eatom"], n + " eatom")
+        _close(r["virial"], g["virial"], n + " virial", atol=1e-8)
+        assert abs(r["energy"] - float(g["energy"])) <= 1e-10 * len(g["ilist"]) * max(1, abs(float(g["energy"])) / len(g["ilist"]))
+
+
+def test_config2_size_properties_64k_atoms():
+    """BASELINE config 2 at full size: properties that need no CPU pass over all atoms
+    (sum F = 0 after the ghost fold, E = sum eatom, virial = sum vatom) plus oracle
+    parity of the site energies of a 512-atom sample."""
+    pos, box = mtpgen.bcc_lattice(32, 32, 32)
+    s = periodic_system(pos, box, None, 7.0)
+    assert s.nlocal == 65536
+    path = os.path.join(POT, "W_L16.mtp")
+    pot = capi.Potential(path)
+    ctx = capi.Context(pot, 0)
+    ctx.set_neighbors(s.ilist, s.first, s.neigh, s.nall)
+    r = ctx.compute(s.x, s.types)
+    F = s.fold_forces(r["f"])
+    assert np.abs(F.sum(0)).max() < 1e-7
+    assert abs(r["energy"] - r["eatom"][: s.nlocal].sum()) < 1e-6
+    _close(r["vatom"][: s.nlocal].sum(0), r["virial"], "virial sum", atol=1e-6)
+    pick = np.random.default_rng(0).choice(s.nlocal, 512, replace=False).astype(np.int32)
+    first = np.zeros(513, np.int32)
+    first[1:] = np.cumsum(s.first[pick + 1] - s.first[pick])
+    neigh = np.concatenate([s.neigh[s.first[i]:s.first[i + 1]] for i in pick])
+    want = _oracle(path).compute(s.x, s.types, pick, first, neigh)
+    _close(r["eatom"][pick], want["eatom"][pick], "sampled eatom")
+    # translation of the whole crystal changes nothing
+    r2 = ctx.compute(s.x + np.array([0.37, -1.1, 2.2]), s.types)
+    _close(r2["f"], r["f"], "translated forces", atol=1e-8)
