@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: atom-steps/s of the MTP force call on a 64k-atom BCC W crystal with
+the level-16 potential (BASELINE.json configs[1]) on N MI355X of one node.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one force call on positions already resident in HBM: zero the force array,
+(N > 1: forward halo of ghost positions over RCCL), the fused MTP kernel with global
+energy and virial tallies, (N > 1: reverse halo of ghost forces).  N > 1 shards the SAME
+65,536 atoms by spatial domain decomposition (strong scaling, as BASELINE.json's metric
+asks).  Rank 0 prints one JSON line; `roofline` prices the dominant kernel against its
+algorithmic HBM bytes and `cpu_baseline` times the CPU oracle on this
+box's host cores in the same run.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6   # vendor vector fp64 peak
+
+
+def algorithmic_bytes(nlist_entries, nall, nlocal):
+    """compulsory traffic of one force call."""
+    return 4 * nlist_entries + 76 * nall + 8 * nlocal
+
+
+def algorithmic_flops_reference(sizes, jc_total, nlocal):
+    """SURVEY.md section 8(d) F_alg: flops the REFERENCE algorithm spends (the native kernel does
+    fewer: it never forms the per-pair Jacobian)."""
+    R, P, Mu, B, T, S = sizes["R"], sizes["P"], sizes["Mu"], sizes["B"], sizes["T"], sizes["S"]
+    return jc_total * (9 + 8 * R + 4 * P + 4 * Mu * R + 34 * B) + nlocal * (9 * T + 2 * S)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--cells", type=int, default=32, help="BCC cells per edge (32 -> 65,536 atoms)")
+    ap.add_argument("--potential", default=os.path.join(ROOT, "potentials", "W_L16.mtp"))
+    ap.add_argument("--variant", default="auto", choices=["auto", "large", "small"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from lammps_mtp_kokkos_amd import capi, mtpgen
+    from lammps_mtp_kokkos_amd.domain import HaloExchange, decompose
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- synthetic workload --------------------------------------------------
+    pos, box = mtpgen.bcc_lattice(args.cells, args.cells, args.cells, a=3.165, jitter=0.05, seed=777)
+    natoms = len(pos)
+    list_cutoff = 7.0
+    plan = decompose(pos, box, None, world, rank, list_cutoff)
+    pot = capi.Potential(args.potential)
+    sizes = pot.sizes
+    ctx = capi.Context(pot, local_rank)
+    ctx.set_variant(dict(auto=0, large=1, small=2)[args.variant])
+    il = torch.from_numpy(plan.ilist).to(dev)
+    fi = torch.from_numpy(plan.first).to(dev)
+    ne = torch.from_numpy(plan.neigh).to(dev)
+    max_nn = int(np.diff(plan.first).max()) if plan.nlocal else 0
+    ctx.set_neighbors_device(il, fi, ne, plan.nall, max_nn)
+    x = torch.from_numpy(plan.x0).to(dev)
+    ty = torch.from_numpy(plan.types).to(dev)
+    f = torch.zeros((plan.nall, 3), dtype=torch.float64, device=dev)
+    ev = torch.zeros(8, dtype=torch.float64, device=dev)
+    halo = HaloExchange(plan, dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    EFLAG, VFLAG = 1, 1
+
+    def step():
+        f.zero_()
+        if world > 1:
+            halo.forward(x)
+        ctx.compute_device(x, ty, f, eflag=EFLAG, vflag=VFLAG, ev_t=ev, stream=stream)
+        if world > 1:
+            halo.reverse(f)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize(stream)
+    ev.zero_()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ev)
+    dt = float(tmax.item())
+    ctx.synchronize(stream)
+    energy_per_atom = float(ev[0].item()) / args.steps / natoms
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, separate pass -----------
+    ctx.set_timing(True)
+    kms = []
+    for _ in range(min(args.steps, 50)):
+        f.zero_()
+        ctx.compute_device(x, ty, f, eflag=EFLAG, vflag=VFLAG, ev_t=ev, stream=stream)
+        kms.append(ctx.last_kernel_ms())
+    ctx.set_timing(False)
+    kernel_ms = float(np.mean(kms))
+
+    # in-cutoff pair count of this rank (for the reference flop model), on the device
+    with torch.no_grad():
+        cnt = torch.diff(fi.long())
+        row = torch.repeat_interleave(torch.arange(plan.nlocal, device=dev), cnt)
+        d = x[ne.long()] - x[row]
+        jc_total = int(((d * d).sum(1) <= pot.info.max_cutoff ** 2).sum().item())
+    bytes_alg = algorithmic_bytes(int(plan.first[-1]), plan.nall, plan.nlocal)
+    flops_ref = algorithmic_flops_reference(sizes, jc_total, plan.nlocal)
+    achieved_gbs = bytes_alg / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    # ---- CPU baseline: the oracle (a port of the reference CPU path), 1 thread, rank 0, N = 1 -----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.pyoracle import Oracle
+        o = Oracle(args.potential)
+        xs = plan.x0
+        nsub = min(plan.nlocal, 16384)
+        sub_first = plan.first[: nsub + 1]
+        sub_neigh = plan.neigh[: sub_first[-1]]
+        passes, tcpu = 0, 0.0
+        while tcpu < args.cpu_seconds and passes < 50:
+            c0 = time.perf_counter()
+            rc = o.compute(xs, plan.types, plan.ilist[:nsub], sub_first, sub_neigh, eflag=EFLAG, vflag=VFLAG)
+            tcpu += time.perf_counter() - c0
+            passes += 1
+        cpu = {"value": nsub * passes / tcpu, "unit": "atom-steps/s", "cores": 1, "kind": "port",
+               "sample": "%d passes over the first %d of the %d atoms (same lattice, potential, list, flags), "
+                         "serial C oracle, %.1f s" % (passes, nsub, natoms, tcpu),
+               "host_cpus": os.cpu_count()}
+        # parity of the timed configuration, sampled: site energies of the sub-list
+        ea = torch.zeros(plan.nall, dtype=torch.float64, device=dev)
+        f.zero_()
+        ctx.compute_device(x, ty, f, eflag=3, vflag=0, eatom_t=ea, ev_t=ev, stream=stream)
+        ctx.synchronize(stream)
+        cpu["max_abs_dE_site_eV"] = float(np.abs(ea.cpu().numpy()[:nsub] - rc["eatom"][:nsub]).max())
+
+    if rank == 0:
+        value = natoms * args.steps / dt
+        info = ctx.launch_info()
+        line = {
+            "metric": "atom-steps/s (64k-atom W, level-16 MTP)", "value": value, "unit": "atom-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%d-atom BCC W (a=3.165 A, +-0.05 A jitter, seed 777), level-16 MTP "
+                                   "(B=%d T=%d S=%d A=%d R=%d Mu=%d), rc=5 A, full list 7 A, eflag=1 vflag=1"
+                                   % (natoms, sizes["B"], sizes["T"], sizes["S"], sizes["A"], sizes["R"], sizes["Mu"]),
+                       "atoms": natoms, "potential": os.path.basename(args.potential),
+                       "parallelism": "domain decomposition %s, RCCL all-to-all halo" % "x".join(map(str, plan.grid))
+                       if world > 1 else "single GPU",
+                       "atoms_rank0": plan.nlocal, "ghosts_rank0": plan.nghost, "list_entries_rank0": int(plan.first[-1]),
+                       "in_cutoff_pairs_rank0": jc_total, "launch": info},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "mtp_wave_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": bytes_alg,
+                         "note": "fused kernel is fp64-VALU/LDS bound, not HBM bound (SURVEY.md 8d); "
+                                 "fp64 fraction below uses the REFERENCE algorithm's flop count",
+                         "fp64_valu": {"achieved": flops_ref / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s",
+                                       "frac": flops_ref / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                       "reference_flops_per_launch": flops_ref}},
+            "cpu_baseline": cpu,
+            "energy_per_atom_eV": energy_per_atom,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

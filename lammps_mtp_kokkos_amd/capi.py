@@ -50,6 +50,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        # torch bundles its own libamdhip64.so.7; importing it first makes this library bind to
+        # that same HIP runtime (one runtime per process) instead of loading /opt/rocm's beside it
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         L.mtp_last_error.restype = C.c_char_p
         for n in EXPORTS:

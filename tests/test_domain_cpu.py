@@ -1,0 +1,90 @@
+"""Domain decomposition + halo exchange on CPU: world_size-2 and -4 `gloo` runs whose
+sharded forces/energies must equal the single-domain result (the oracle does the
+per-shard force call here; on the GPU box the HIP path does)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lammps_mtp_kokkos_amd import mtpgen
+from lammps_mtp_kokkos_amd.domain import HaloExchange, decompose, rank_grid
+from lammps_mtp_kokkos_amd.driver import periodic_system
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+POTF = os.path.join(ROOT, "potentials", "WRe_L10_cfg.almtp")
+
+
+def _global_system():
+    pos, box = mtpgen.bcc_lattice(3, 3, 4, seed=31)
+    types = np.random.default_rng(2).integers(1, 3, size=len(pos)).astype(np.int32)
+    return pos, box, types
+
+
+def _worker(rank, world, port, out):
+    from oracle.pyoracle import Oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pos, box, types = _global_system()
+        plan = decompose(pos, box, types, world, rank, 7.0)
+        halo = HaloExchange(plan, torch.device("cpu"))
+        x = torch.from_numpy(plan.x0.copy())
+        x[plan.nlocal:] = 0.0                      # ghosts must come from the forward halo
+        halo.forward(x)
+        assert np.abs(x.numpy() - plan.x0).max() < 1e-12
+        o = Oracle(POTF)
+        r = o.compute(x.numpy(), plan.types, plan.ilist, plan.first, plan.neigh, eflag=3, vflag=1)
+        f = torch.from_numpy(r["f"].copy())
+        halo.reverse(f)
+        ev = torch.tensor([r["energy"]] + list(r["virial"]))
+        dist.all_reduce(ev)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (plan.owned_global, f[: plan.nlocal].numpy(), r["eatom"][: plan.nlocal]))
+        if rank == 0:
+            n = len(pos)
+            F = np.zeros((n, 3))
+            E = np.zeros(n)
+            seen = np.zeros(n, int)
+            for ids, ff, ee in gathered:
+                F[ids] = ff
+                E[ids] = ee
+                seen[ids] += 1
+            assert (seen == 1).all()
+            np.savez(out, F=F, E=E, ev=ev.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_equals_single_domain(tmp_path, world):
+    from oracle.pyoracle import Oracle
+    out = str(tmp_path / "res.npz")
+    port = 29600 + world + (os.getpid() % 200)
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    got = np.load(out)
+    pos, box, types = _global_system()
+    pos = pos - np.floor(pos / box) * box
+    s = periodic_system(pos, box, types, 7.0)
+    r = Oracle(POTF).compute(s.x, s.types, s.ilist, s.first, s.neigh, eflag=3, vflag=1)
+    F = s.fold_forces(r["f"])
+    np.testing.assert_allclose(got["F"], F, rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(got["E"], r["eatom"][: s.nlocal], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(got["ev"][0], r["energy"], rtol=1e-11)
+    np.testing.assert_allclose(got["ev"][1:], r["virial"], rtol=1e-9, atol=1e-9)
+
+
+def test_plan_bookkeeping():
+    pos, box, types = _global_system()
+    for world in (1, 2, 4, 8):
+        plans = [decompose(pos, box, types, world, r, 7.0, with_lists=False) for r in range(world)]
+        assert sum(p.nlocal for p in plans) == len(pos)
+        assert np.prod(rank_grid(world)) == world
+        for r, p in enumerate(plans):
+            assert sum(p.recv_counts) == p.nghost and sum(p.send_counts) == len(p.send_idx)
+            for q, pq in enumerate(plans):
+                assert p.send_counts[q] == pq.recv_counts[r]
+            assert (p.send_idx >= 0).all() and (p.send_idx < p.nlocal).all()

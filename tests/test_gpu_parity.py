@@ -103,8 +103,8 @@ def test_ragged_lists_empty_rows_and_subset_ilist():
             r = r[: len(r) // 3]          # truncated row
         if ii % 11 == 0:
             r = r[:0]                     # atom with no neighbours at all
-        r = r | (int(rng.integers(0, 4)) << 30)      # LAMMPS special bits above NEIGHMASK
-        rows.append(r.astype(np.int32))
+        r = (r.astype(np.uint32) | np.uint32(int(rng.integers(0, 4)) << 30)).view(np.int32)   # LAMMPS special bits
+        rows.append(r)
     first = np.zeros(len(keep) + 1, np.int32)
     first[1:] = np.cumsum([len(r) for r in rows])
     s.ilist, s.first, s.neigh = keep, first, np.concatenate(rows).astype(np.int32)
