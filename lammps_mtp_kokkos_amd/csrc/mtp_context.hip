@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -63,9 +64,9 @@ struct mtp_context {
   int variant = MTP_VARIANT_AUTO;
   int num_cus = 256;
   // potential tables
-  DevBuf<double> d_radial, d_seed_val, d_lin, d_species, d_inv_active;
-  DevBuf<int> d_basic_pack, d_slot_of, d_level_off, d_seed_idx, d_map;
-  DevBuf<int4> d_rows;
+  DevBuf<double> d_species, d_inv_active;
+  DevBuf<MtpRow8> d_rows;
+  DevBuf<unsigned char> d_blob;
   // neighbour list
   DevBuf<int> d_ilist, d_first, d_neigh;
   const int *ilist = nullptr, *first = nullptr, *neigh = nullptr;   // active (owned or caller's)
@@ -91,37 +92,70 @@ struct mtp_context {
   void plan();
 };
 
-// Choose the neighbour tile and the workgroup shape from the LDS budget (160 KiB / CU).
+// Choose the neighbour tile and the workgroup shape from the LDS budget (160 KiB / CU):
+// every workgroup carries one copy of the table blob plus one private region per wavefront.
 void mtp_context::plan()
 {
   const mtp_potential &p = *pot;
   const int A = p.alpha_moment_count, P = p.max_alpha_index_basic;
-  const int stride = 2 * p.slot_count + 6 * P;
+  const int tab_rows = 2 * p.slot_count + 3 * (P + 1);
+  int KL = 16, KB = 1;
+  (void) mtp_pick_shape(p.alpha_index_basic_count, &KL, &KB);
+  const int m_doubles = std::max(A, 4 * KL * KB);
   const int cap = std::max(64, (max_numneigh + 63) / 64 * 64);
+  const size_t LDS = 160 * 1024;
+  const size_t blob = (size_t) base.blob_bytes;
   auto wave_bytes = [&](int nt) {
-    size_t dbl = (size_t) 2 * A + (size_t) nt * stride + 5 * (size_t) nt + 64;
+    size_t dbl = (size_t) A + m_doubles + (size_t) tab_rows * (nt + 2) + 5 * (size_t) nt + 144;
     size_t ints = (size_t) 2 * nt + cap;
     return (dbl * 8 + ints * 4 + 15) / 16 * 16;
   };
-  // prefer one tile for typical neighbour counts (32) but drop to 16 when that would
-  // leave fewer than 6 wavefronts per CU
-  NT = 32;
-  if (160 * 1024 / wave_bytes(32) < 6 && 160 * 1024 / wave_bytes(16) > 160 * 1024 / wave_bytes(32)) NT = 16;
+  // waves per CU for a (tile, waves-per-workgroup) choice; registers allow 8 (2 per SIMD)
+  auto waves_per_cu = [&](int nt, int w) {
+    size_t blk = blob + w * wave_bytes(nt);
+    if (blk > LDS) return 0;
+    return std::min<int>(8, (int) (LDS / blk) * w);
+  };
+  const int wmax = (variant == MTP_VARIANT_SMALL || (variant == MTP_VARIANT_AUTO && inum < num_cus * 16))
+      ? 2 : MTP_MAX_WPB;
+  int best_nt = 0, best_w = 0, best = 0;
+  for (int nt : {32})
+    for (int w = 1; w <= wmax; w++) {
+      int v = waves_per_cu(nt, w);
+      // prefer occupancy; at equal occupancy the larger tile, then fewer waves per workgroup
+      // when the shared blob is small (finer-grained scheduling), more when it is big
+      if (v > best || (v == best && v > 0 && nt == best_nt && blob > 16384 && w > best_w)) {
+        best = v;
+        best_nt = nt;
+        best_w = w;
+      }
+    }
+  if (best == 0) throw HipFail{hipErrorInvalidValue, "potential + neighbour list exceed one CU's LDS"};
+  if (variant == MTP_VARIANT_SMALL) {   // one wavefront per workgroup: finest spread of few atoms
+    best_w = 1;
+    best = waves_per_cu(best_nt, 1);
+  }
+  // tuning overrides (benchmarks only)
+  if (const char *e = std::getenv("MTP_NT")) {
+    int v = std::atoi(e);
+    if (v == 32 && waves_per_cu(v, best_w) > 0) best_nt = v;
+  }
+  if (const char *e = std::getenv("MTP_WPB")) {
+    int v = std::atoi(e);
+    if (v >= 1 && v <= MTP_MAX_WPB && waves_per_cu(best_nt, v) > 0) best_w = v;
+  }
+  best = std::max(1, waves_per_cu(best_nt, best_w));
+  NT = best_nt;
+  wpb = best_w;
   size_t wb = wave_bytes(NT);
-  if (wb > 160 * 1024) throw HipFail{hipErrorInvalidValue, "potential + neighbour list exceed one CU's LDS"};
   wave_doubles = (int) (wb / 8);
-  int max_waves_per_cu = (int) std::min<size_t>(160 * 1024 / wb, 16);   // <= 16: VGPR-bound anyway
-  // LARGE: 4 wavefronts (4 atoms) per workgroup; SMALL: 1 wavefront per workgroup so few
-  // atoms still spread over all CUs
-  int want = (variant == MTP_VARIANT_SMALL) ? 1 : 4;
-  if (variant == MTP_VARIANT_AUTO && inum < num_cus * 8) want = 1;
-  wpb = std::max(1, std::min(want, max_waves_per_cu));
-  lds_bytes = wb * wpb;
-  const int blocks_per_cu = std::max(1, max_waves_per_cu / wpb);
+  lds_bytes = blob + wb * wpb;
+  const int blocks_per_cu = std::max(1, best / wpb);
   const int need = (inum + wpb - 1) / wpb;
-  grid = std::max(1, std::min(need, num_cus * blocks_per_cu * 4));
+  grid = std::max(1, std::min(need, num_cus * blocks_per_cu));
   base.NT = NT;
-  base.stride = stride;
+  base.tab_rows = tab_rows;
+  base.m_doubles = m_doubles;
   base.cj_cap = cap;
   base.wave_doubles = wave_doubles;
 }
@@ -233,17 +267,47 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     c->num_cus = prop.multiProcessorCount;
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     hipStream_t st = c->stream;
-    c->d_radial.upload(pot->radial_basis_coeffs, st);
-    c->d_basic_pack.upload(pot->basic_pack, st);
-    c->d_slot_of.upload(pot->slot_of, st);
-    static_assert(sizeof(MtpRow) == sizeof(int4), "row layout");
-    c->d_rows.upload(reinterpret_cast<const int4 *>(pot->rows_by_level.data()), pot->rows_by_level.size(), st);
-    c->d_level_off.upload(pot->level_offset, st);
-    c->d_seed_idx.upload(pot->seed_idx, st);
-    c->d_seed_val.upload(pot->seed_val, st);
-    c->d_map.upload(pot->alpha_moment_mapping, st);
-    c->d_lin.upload(pot->linear_coeffs, st);
     c->d_species.upload(pot->species_coeffs, st);
+    // packed rows (8 B each): moment ids in 16 bits, multiplicity in a signed 16 bits
+    if (pot->alpha_moment_count > 65535) {
+      copy_err("alpha_moments_count above 65535 is not supported by this build", err, errlen);
+      delete c;
+      return MTP_ERR_LIMIT;
+    }
+    std::vector<MtpRow8> rows8(pot->rows_by_level.size());
+    for (size_t k = 0; k < rows8.size(); k++) {
+      const MtpRow &r = pot->rows_by_level[k];
+      if (r.mult > 32767 || r.mult < -32768) {
+        copy_err("alpha_index_times multiplicity outside 16 bits is not supported by this build", err, errlen);
+        delete c;
+        return MTP_ERR_LIMIT;
+      }
+      rows8[k].lo = (uint32_t) r.a0 | ((uint32_t) r.a1 << 16);
+      rows8[k].hi = (uint32_t) r.a3 | (((uint32_t) r.mult & 0xffffu) << 16);
+    }
+    c->d_rows.upload(rows8.data(), rows8.size(), st);
+    // table blob copied into LDS by every workgroup
+    MtpDevParams &bb = c->base;
+    bb.rows_in_lds = rows8.size() * sizeof(MtpRow8) <= 24 * 1024;
+    std::vector<unsigned char> blob;
+    auto put = [&](const void *src, size_t bytes) {
+      size_t off = (blob.size() + 7) / 8 * 8;
+      blob.resize(off + bytes, 0);
+      if (bytes) std::memcpy(blob.data() + off, src, bytes);
+      return (int) off;
+    };
+    bb.off_rows = bb.rows_in_lds ? put(rows8.data(), rows8.size() * sizeof(MtpRow8)) : 0;
+    bb.off_level = put(pot->level_offset.data(), pot->level_offset.size() * sizeof(int32_t));
+    bb.off_slot = put(pot->slot_of.data(), pot->slot_of.size() * sizeof(int32_t));
+    bb.off_radial = put(pot->radial_basis_coeffs.data(), pot->radial_basis_coeffs.size() * sizeof(double));
+    bb.off_seed_idx = put(pot->seed_idx.data(), pot->seed_idx.size() * sizeof(int32_t));
+    bb.off_seed_val = put(pot->seed_val.data(), pot->seed_val.size() * sizeof(double));
+    bb.off_map = put(pot->alpha_moment_mapping.data(), pot->alpha_moment_mapping.size() * sizeof(int32_t));
+    bb.off_lin = put(pot->linear_coeffs.data(), pot->linear_coeffs.size() * sizeof(double));
+    bb.off_pack = put(pot->basic_pack.data(), pot->basic_pack.size() * sizeof(int32_t));
+    blob.resize((blob.size() + 15) / 16 * 16, 0);
+    bb.blob_bytes = (int) blob.size();
+    c->d_blob.upload(blob.data(), blob.size(), st);
     if (pot->has_selection) c->d_inv_active.upload(pot->inverse_active_set, st);
     c->d_ev_slots.reserve((size_t) MTP_EV_SLOTS * 8);
     HIP_CHECK(hipMemsetAsync(c->d_ev_slots.ptr, 0, (size_t) MTP_EV_SLOTS * 8 * sizeof(double), st));
@@ -270,21 +334,16 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     b.rmax = pot->max_cutoff;
     b.scaling = pot->scaling;
     b.cutsq = pot->max_cutoff * pot->max_cutoff;   // pair_mtp.cpp:449,456
-    b.radial_coeffs = c->d_radial.ptr;
-    b.basic_pack = c->d_basic_pack.ptr;
-    b.slot_of = c->d_slot_of.ptr;
+    b.blob = c->d_blob.ptr;
     b.rows = c->d_rows.ptr;
-    b.level_off = c->d_level_off.ptr;
-    b.seed_idx = c->d_seed_idx.ptr;
-    b.seed_val = c->d_seed_val.ptr;
-    b.map = c->d_map.ptr;
-    b.lin = c->d_lin.ptr;
     b.species_coeffs = c->d_species.ptr;
+    b.inv_mu = 1.0f / (float) pot->radial_func_count;
     b.inv_active = pot->has_selection ? c->d_inv_active.ptr : nullptr;
     b.ev_slots = c->d_ev_slots.ptr;
     b.err_flag = c->d_err.ptr;
-    if ((pot->alpha_index_basic_count + 63) / 64 > 8) {
-      copy_err("alpha_index_basic_count above 512 is not supported by this build", err, errlen);
+    int kl_ = 0, kb_ = 0;
+    if (mtp_pick_shape(pot->alpha_index_basic_count, &kl_, &kb_) != 0) {
+      copy_err("alpha_index_basic_count above 640 is not supported by this build", err, errlen);
       delete c;
       return MTP_ERR_LIMIT;
     }

@@ -7,44 +7,60 @@
 #include <cstdint>
 
 #define MTP_EV_SLOTS 1024   // per-wave energy/virial tally slots (8 doubles each)
+#define MTP_MAX_WPB 8       // wavefronts per workgroup (512 threads)
+
+// A times row packed in 8 bytes: lo = a0 | a1 << 16, hi = a3 | (mult & 0xffff) << 16
+struct MtpRow8 {
+  uint32_t lo, hi;
+};
 
 struct MtpDevParams {
-  // potential (device pointers)
+  // potential sizes
   int Sp, R, Mu, P, A, B, T, S, C;
   int nslot, nlevels, nseed;
   double rmin, rmax, scaling, cutsq;
-  const double *radial_coeffs;   // [(t1*Sp+t2)*Mu*R + mu*R + ri]
-  const int *basic_pack;         // [B] slot | a<<8 | b<<12 | c<<16
-  const int *slot_of;            // [Mu*P]
-  const int4 *rows;              // [T] {a0,a1,mult,a3} sorted by dependency level
-  const int *level_off;          // [nlevels+1]
-  const int *seed_idx;           // [nseed]
-  const double *seed_val;
-  const int *map;                // [S]
-  const double *lin;             // [S]
-  const double *species_coeffs;  // [Sp]
-  const double *inv_active;      // [C][C] or null
+  // Read-mostly tables, one contiguous blob in HBM that every workgroup copies into the
+  // head of its LDS once; offsets in bytes from the blob start (all 8-byte aligned).
+  const unsigned char *blob;
+  int blob_bytes;          // multiple of 16
+  int off_rows;            // MtpRow8[T]   (only when rows_in_lds)
+  int off_level;           // int[nlevels+1]
+  int off_slot;            // int[Mu*P]
+  int off_radial;          // double[Sp*Sp*Mu*R]
+  int off_seed_idx;        // int[nseed]
+  int off_seed_val;        // double[nseed]
+  int off_map;             // int[S]
+  int off_lin;             // double[S]
+  int off_pack;            // int[B] slot | a<<8 | b<<12 | c<<16
+  int rows_in_lds;
+  const MtpRow8 *rows;     // [T] by level, in HBM (always valid)
+  const double *species_coeffs;
+  const double *inv_active;   // [C][C] or null
   // system
   int inum, nall;
   const int *ilist, *first, *neigh;
-  const double *x;               // [nall][3]
-  const int *type;               // [nall] 1-based
+  const double *x;         // [nall][3]
+  const int *type;         // [nall] 1-based
   // outputs
-  double *f;                     // [nall][3] accumulated
-  double *eatom;                 // [nall] or null
-  double *vatom;                 // [nall][6] or null
-  double *ev_slots;              // [MTP_EV_SLOTS][8]
-  double *grades;                // [nall] or null
-  double *max_grade;             // [1] or null
-  double *coeff_ders;            // [C] or null
+  double *f;               // [nall][3] accumulated
+  double *eatom;           // [nall] or null
+  double *vatom;           // [nall][6] or null
+  double *ev_slots;        // [MTP_EV_SLOTS][8]
+  double *grades;          // [nall] or null
+  double *max_grade;       // [1] or null
+  double *coeff_ders;      // [C] or null
   int *err_flag;
   int eflag, vflag, grade_flag;
   // launch geometry
-  int NT;                        // neighbours per LDS tile (multiple of 16)
-  int stride;                    // doubles per neighbour record = 2*nslot + 6*P
-  int cj_cap;                    // capacity of the compacted id list
-  int wave_doubles;              // LDS doubles per wavefront
+  int NT;                  // neighbours per LDS tile: 32 or 16 (table row pitch = NT + 2 doubles)
+  int tab_rows;            // table rows = 2*nslot + 3*(P+1)
+  int cj_cap;              // capacity of the compacted id list
+  int wave_doubles;        // LDS doubles per wavefront
+  int m_doubles;           // doubles of the moment region = max(A, 4*KL*KB)
+  float inv_mu;            // 1 / Mu
 };
 
+// lane-grid shape for B basics: KL k-lanes x KB basics per lane; -1 when B is too large
+int mtp_pick_shape(int B, int *KL, int *KB);
 hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);
 hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st);

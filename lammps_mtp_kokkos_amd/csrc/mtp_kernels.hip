@@ -5,20 +5,26 @@
 // and the per-pair Jacobian the reference spills to HBM
 // (d_moment_jacobian[N][J][B][3], pair_mtp_kokkos.cpp:270-282) is never formed:
 //
+//   0. tables       every workgroup copies the read-mostly potential tables (packed times
+//                   rows, level offsets, radial coefficients, slots, seeds) into the head
+//                   of its LDS once; a persistent grid-stride loop over atoms follows
 //   1. compaction   lanes = list entries: r^2 <= rc^2 test (pair_mtp.cpp:120-127),
-//                   ballot/prefix -> in-cutoff neighbour ids in LDS
-//   2. tile tables  per in-cutoff neighbour, in LDS: g[mu,nu] = f_mu(r)/r^nu and
-//                   dg/dr (Chebyshev recurrence + radial contraction,
-//                   mtp_rb_chevbyshev_basis.cpp:29-54, pair_mtp.cpp:139-166) and the
-//                   coordinate powers x^p, p x^(p-1) (pair_mtp.cpp:133-136)
-//   3. basic moments lanes = basic index k: M_k += g * x^a y^b z^c over the tile in
-//                   registers (pair_mtp.cpp:154-172); no cross-lane reduction
+//                   ballot/prefix -> in-cutoff neighbours in LDS
+//   2. tile tables  per in-cutoff neighbour n, entry-major in LDS (row e, column n):
+//                   g[mu,nu](n) = f_mu(r)/r^nu and dg/dr (Chebyshev recurrence + radial
+//                   contraction, mtp_rb_chevbyshev_basis.cpp:29-54, pair_mtp.cpp:139-166)
+//                   and the coordinate powers x^p (pair_mtp.cpp:133-136)
+//   3. basic moments the wavefront is NG neighbour groups x KL k-lanes: lane (q, kl) owns the
+//                   basics k = kl + KL t and the neighbours n = q + NG m, and accumulates
+//                   M_k += g x^a y^b z^c in registers (pair_mtp.cpp:154-172); the table
+//                   row pitch is a compile-time constant so every LDS read is base
+//                   register + immediate; NG-way shuffle sum at the end
 //   4. products     lanes = times rows, one dependency level at a time, moments and
-//                   adjoints in LDS (pair_mtp.cpp:196-233)
-//   5. forces       lanes = k again: each lane contracts its adjoint D_k with the
-//                   analytic d(M_k)/d(r_ij) rebuilt from the LDS tables
-//                   (pair_mtp.cpp:174-191, 236-246), a butterfly transpose-reduce sums
-//                   over k for 16 neighbours at a time, then lanes = neighbours scatter
+//                   adjoints in LDS with ds_add_f64 (pair_mtp.cpp:196-233)
+//   5. forces       same lane grid: each lane contracts its adjoints D_k with the analytic
+//                   d(M_k)/d(r_ij) rebuilt from the LDS tables (pair_mtp.cpp:174-191,
+//                   236-246); a butterfly transpose-reduce over the KL k-lanes sums over
+//                   k for KL/4 neighbours per group at once; 16 lanes then scatter
 //                   f_j -= F_ij with fp64 HBM atomics and tally the virial
 //                   (pair_mtp.cpp:248-277)
 //
@@ -39,10 +45,7 @@ __device__ __forceinline__ void wave_fence()
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ double shfl_xor_f64(double v, int mask)
-{
-  return __shfl_xor(v, mask, 64);
-}
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -56,9 +59,21 @@ __device__ __forceinline__ void lds_add(double *p, double v)
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Butterfly transpose-reduce: every lane enters with N partial sums v[0..N); on exit
-// lane l holds in v[0] the wave-wide total of entry (l mod N) ... for N = 64 exactly
-// entry l.  N-1 adds and N-1 exchanges per lane instead of N*log2(64).
+// LDS read at (32-bit LDS byte address + compile-time byte offset): the offset lands in the
+// ds_read immediate field, so inner loops spend no VALU on addressing.
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+__device__ __forceinline__ unsigned lds_addr(const double *p)
+{
+  return (unsigned) (size_t) (lds_cdouble *) p;
+}
+__device__ __forceinline__ double lds_ld(unsigned base, int off_doubles)   // off: constant after unrolling
+{
+  return *(lds_cdouble *) (size_t) (base + 8u * (unsigned) off_doubles);
+}
+
+// Butterfly transpose-reduce over the lane bits below N: every lane enters with N partial
+// sums v[0..N); on exit v[0] of lane l holds entry (l mod N) summed over the N lanes that
+// differ from l only in those bits.  N-1 adds and N-1 exchanges instead of N*log2(N).
 template <int N> struct Butterfly {
   static __device__ __forceinline__ void run(double *v, int lane)
   {
@@ -77,54 +92,68 @@ template <> struct Butterfly<1> {
   static __device__ __forceinline__ void run(double *, int) {}
 };
 
-struct WaveLds {
-  double *M, *D, *tab, *nbx, *nby, *nbz, *nbr, *nbi, *red;
-  int *nbj, *nbjt, *cj;
+struct BlockTables {   // views into the workgroup-shared head of LDS
+  const MtpRow8 *rows;
+  const int *level, *slot, *seed_idx, *map, *pack;
+  const double *radial, *seed_val, *lin;
 };
 
-__device__ __forceinline__ WaveLds carve(double *base, const MtpDevParams &p)
-{
-  WaveLds w;
-  w.M = base;
-  w.D = w.M + p.A;
-  w.tab = w.D + p.A;
-  w.nbx = w.tab + (size_t) p.NT * p.stride;
-  w.nby = w.nbx + p.NT;
-  w.nbz = w.nby + p.NT;
-  w.nbr = w.nbz + p.NT;
-  w.nbi = w.nbr + p.NT;
-  w.red = w.nbi + p.NT;
-  w.nbj = reinterpret_cast<int *>(w.red + 64);
-  w.nbjt = w.nbj + p.NT;
-  w.cj = w.nbjt + p.NT;
-  return w;
-}
-
-// Phase 2: tables of one tile of nt <= NT in-cutoff neighbours starting at cj[t0].
-__device__ __forceinline__ void build_tile(const MtpDevParams &p, const WaveLds &w, int t0, int nt,
-                                           double xi0, double xi1, double xi2, int itype, int lane)
-{
-  if (lane < nt) {
-    const int j = w.cj[t0 + lane];
-    const double dx = p.x[3 * (size_t) j] - xi0, dy = p.x[3 * (size_t) j + 1] - xi1,
-                 dz = p.x[3 * (size_t) j + 2] - xi2;
-    const double r = sqrt(dx * dx + dy * dy + dz * dz);
-    w.nbx[lane] = dx;
-    w.nby[lane] = dy;
-    w.nbz[lane] = dz;
-    w.nbr[lane] = r;
-    w.nbi[lane] = 1.0 / r;
-    w.nbj[lane] = j;
-    w.nbjt[lane] = p.type[j] - 1;
+template <int PITCH> struct WaveLds {
+  static constexpr int NT = PITCH - 2;
+  double *M, *D, *tab, *nbx, *nby, *nbz, *nbr, *nbi, *red;
+  int *nbj, *nbjt, *cj;
+  __device__ __forceinline__ WaveLds(double *base, const MtpDevParams &p)
+  {
+    M = base;
+    D = M + p.m_doubles;   // M region also hosts the exponent-weighted adjoints in phase 5
+    tab = D + p.A;
+    nbx = tab + (size_t) p.tab_rows * PITCH;
+    nby = nbx + NT;
+    nbz = nby + NT;
+    nbr = nbz + NT;
+    nbi = nbr + NT;
+    red = nbi + NT;   // 144 doubles
+    nbj = reinterpret_cast<int *>(red + 144);
+    nbjt = nbj + NT;
+    cj = nbjt + NT;
   }
-  wave_fence();
-  const int Mu = p.Mu, P = p.P, R = p.R, ns = p.nslot;
+};
+
+// Phase 2: tables of one tile; columns [0, ntp) are written, ntp = nt rounded up to the
+// neighbour-group count with dummy neighbours sitting exactly on the cutoff (g = dg = 0).
+template <int PITCH>
+__device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTables &bt, const WaveLds<PITCH> &w,
+                                           int t0, int cnt, int ntp, bool gather, double xi0, double xi1,
+                                           double xi2, int i, int itype, int lane)
+{
+  if (gather) {
+    if (lane < ntp) {
+      const bool real = t0 + lane < cnt;
+      const int j = real ? w.cj[t0 + lane] : i;
+      double dx = 0, dy = 0, dz = 0, r = p.rmax;
+      if (real) {
+        dx = p.x[3 * (size_t) j] - xi0;
+        dy = p.x[3 * (size_t) j + 1] - xi1;
+        dz = p.x[3 * (size_t) j + 2] - xi2;
+        r = sqrt(dx * dx + dy * dy + dz * dz);
+      }
+      w.nbx[lane] = dx;
+      w.nby[lane] = dy;
+      w.nbz[lane] = dz;
+      w.nbr[lane] = r;
+      w.nbi[lane] = 1.0 / r;
+      w.nbj[lane] = j;
+      w.nbjt[lane] = real ? p.type[j] - 1 : itype;
+    }
+    wave_fence();
+  }
+  const int Mu = p.Mu, P = p.P, R = p.R;
   const double span = p.rmax - p.rmin, mult = 2.0 / span;
-  for (int idx = lane; idx < nt * Mu; idx += 64) {
-    const int n = idx / Mu, mu = idx - n * Mu;
+  for (int idx = lane; idx < ntp * Mu; idx += 64) {
+    const int n = __float2int_rz((idx + 0.5f) * p.inv_mu), mu = idx - n * Mu;
     const double r = w.nbr[n], inv = w.nbi[n];
     const int jt = w.nbjt[n];
-    const double *c = p.radial_coeffs + ((size_t) (itype * p.Sp + jt) * Mu + mu) * R;
+    const double *c = bt.radial + ((itype * p.Sp + jt) * Mu + mu) * R;
     // Chebyshev values/derivatives by recurrence, contracted on the fly
     const double d = r - p.rmax;
     const double ksi = (2.0 * r - (p.rmin + p.rmax)) / span;
@@ -145,59 +174,96 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const WaveLds 
       e0 = e1;
       e1 = e2;
     }
-    double *rec = w.tab + (size_t) n * p.stride;
+    double *col = w.tab + n;
+    const int *sl = bt.slot + mu * P;
     double rp = 1.0;
     for (int nu = 0; nu < P; nu++) {
-      const int s = p.slot_of[mu * P + nu];
+      const int s = sl[nu];
       const double g = val * rp;
       if (s >= 0) {
-        rec[s] = g;                                 // f_mu / r^nu
-        rec[ns + s] = der * rp - nu * g * inv;      // d/dr (f_mu / r^nu)
+        col[(2 * s) * PITCH] = g;                                // f_mu / r^nu
+        col[(2 * s + 1) * PITCH] = der * rp - nu * g * inv;      // d/dr (f_mu / r^nu)
       }
       rp *= inv;
     }
   }
-  for (int idx = lane; idx < nt * 3; idx += 64) {
-    const int n = idx / 3, ax = idx - 3 * n;
+  for (int idx = lane; idx < ntp * 3; idx += 64) {
+    const int n = __float2int_rz((idx + 0.5f) * (1.0f / 3.0f)), ax = idx - 3 * n;
     const double u = ax == 0 ? w.nbx[n] : (ax == 1 ? w.nby[n] : w.nbz[n]);
-    double *pw = w.tab + (size_t) n * p.stride + 2 * ns + ax * P;
-    double *dpw = pw + 3 * P;
+    // rows of one axis: [0] = 0 ("u^-1" partner of the factor a = 0), [1 + q] = u^q
+    double *col = w.tab + (size_t) (2 * p.nslot + ax * (P + 1) + 1) * PITCH + n;
     double cur = 1.0;
-    pw[0] = 1.0;
-    dpw[0] = 0.0;
+    col[0] = 1.0;
     for (int q = 1; q < P; q++) {
-      dpw[q] = q * cur;   // q u^(q-1)
       cur *= u;
-      pw[q] = cur;
+      col[q * PITCH] = cur;
     }
   }
   wave_fence();
 }
 
-template <int KB> __global__ void __launch_bounds__(256) mtp_wave_kernel(const MtpDevParams p)
+template <int KL, int KB, int PITCH>
+__global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
 {
+  constexpr int NT = PITCH - 2;          // neighbours per tile (32 or 16)
+  constexpr int NG = 64 / KL;            // neighbour groups in the wavefront
+  constexpr int NPG = NT / NG;           // neighbours per group per tile
+  constexpr int BATCH = KL / 4;          // neighbours per group per butterfly
+  constexpr int NBATCH = NPG / BATCH;    // = NT / 16
+  static_assert(NPG % BATCH == 0 && NBATCH >= 1, "tile/batch shape");
+
   extern __shared__ double lds[];
+  unsigned char *sh = reinterpret_cast<unsigned char *>(lds);
+  // ---- 0. workgroup-shared tables ---------------------------------------------------------
+  for (int o = threadIdx.x * 16; o < p.blob_bytes; o += blockDim.x * 16)
+    *reinterpret_cast<uint4 *>(sh + o) = *reinterpret_cast<const uint4 *>(p.blob + o);
+  __syncthreads();
+  BlockTables bt;
+  bt.rows = reinterpret_cast<const MtpRow8 *>(sh + p.off_rows);
+  bt.level = reinterpret_cast<const int *>(sh + p.off_level);
+  bt.slot = reinterpret_cast<const int *>(sh + p.off_slot);
+  bt.radial = reinterpret_cast<const double *>(sh + p.off_radial);
+  bt.seed_idx = reinterpret_cast<const int *>(sh + p.off_seed_idx);
+  bt.seed_val = reinterpret_cast<const double *>(sh + p.off_seed_val);
+  bt.map = reinterpret_cast<const int *>(sh + p.off_map);
+  bt.lin = reinterpret_cast<const double *>(sh + p.off_lin);
+  bt.pack = reinterpret_cast<const int *>(sh + p.off_pack);
+  const bool rows_lds = p.rows_in_lds != 0;
+
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  // wave-uniform by construction: tell the compiler, so per-atom state lives in SGPRs
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wpb = blockDim.x >> 6;
-  const WaveLds w = carve(lds + (size_t) wave * p.wave_doubles, p);
+  const int kl = lane & (KL - 1), q = lane / KL;
+  const WaveLds<PITCH> w(lds + (p.blob_bytes >> 3) + (size_t) wave * p.wave_doubles, p);
   const int ns = p.nslot, P = p.P;
 
-  // per-lane descriptors of the basics this lane owns: k = lane + 64 t
-  int og[KB], oxa[KB], oyb[KB], ozc[KB];
+  // the three "power -1" rows stay zero for the whole launch
+  for (int c = lane; c < 3 * NT; c += 64) {
+    const int ax = c / NT, n = c - ax * NT;
+    w.tab[(size_t) (2 * ns + ax * (P + 1)) * PITCH + n] = 0.0;
+  }
+
+  // per-lane descriptors of the basics this lane owns (k = kl + KL t): LDS row bases for
+  // this lane's neighbour column q; the partner row (dg, next power) is +PITCH
+  unsigned pg[KB], px[KB], py[KB], pz[KB];   // LDS byte addresses
   bool kval[KB];
 #pragma unroll
   for (int t = 0; t < KB; t++) {
-    const int k = lane + 64 * t;
+    const int k = kl + KL * t;
     kval[t] = k < p.B;
-    const int pk = kval[t] ? p.basic_pack[k] : 0;
-    og[t] = pk & 255;
-    oxa[t] = 2 * ns + ((pk >> 8) & 15);
-    oyb[t] = 2 * ns + P + ((pk >> 12) & 15);
-    ozc[t] = 2 * ns + 2 * P + ((pk >> 16) & 15);
+    const int pk = kval[t] ? bt.pack[k] : 0;
+    const int a = (pk >> 8) & 15, b = (pk >> 12) & 15, c = (pk >> 16) & 15;
+    pg[t] = lds_addr(w.tab + (size_t) (2 * (pk & 255)) * PITCH + q);
+    px[t] = lds_addr(w.tab + (size_t) (2 * ns + a) * PITCH + q);         // row of x^(a-1)
+    py[t] = lds_addr(w.tab + (size_t) (2 * ns + (P + 1) + b) * PITCH + q);
+    pz[t] = lds_addr(w.tab + (size_t) (2 * ns + 2 * (P + 1) + c) * PITCH + q);
+    // one finished address per register: stops the optimiser from re-splitting them into
+    // base + row offset (which costs a v_add per LDS read in the inner loops)
+    asm volatile("" : "+v"(pg[t]), "+v"(px[t]), "+v"(py[t]), "+v"(pz[t]));
   }
 
-  double ev_acc[7] = {0, 0, 0, 0, 0, 0, 0};   // lane-0 tallies of this wave: energy + virial
+  double tally = 0.0;   // lane 9: energy, lanes 3..8: virial components of this wave's atoms
 
   for (int ii = blockIdx.x * wpb + wave; ii < p.inum; ii += gridDim.x * wpb) {
     const int i = p.ilist[ii];
@@ -209,181 +275,263 @@ template <int KB> __global__ void __launch_bounds__(256) mtp_wave_kernel(const M
     const double xi0 = p.x[3 * (size_t) i], xi1 = p.x[3 * (size_t) i + 1], xi2 = p.x[3 * (size_t) i + 2];
     const int jbeg = p.first[ii], jnum = p.first[ii + 1] - jbeg;
 
-    // ---- 1. compaction --------------------------------------------------------------------
+    // ---- 1. compaction (the first NT survivors go straight into the tile arrays) --------
     int cnt = 0;
     for (int c0 = 0; c0 < jnum; c0 += 64) {
       const int jj = c0 + lane;
       bool in = false;
-      int j = 0;
+      int j = 0, jt = 0;
+      double dx = 0, dy = 0, dz = 0, r2 = 1.0;
       if (jj < jnum) {
         j = p.neigh[jbeg + jj] & MTP_NEIGHMASK;
-        const int jt = p.type[j] - 1;
+        jt = p.type[j] - 1;
         if (jt < 0 || jt >= p.Sp) {   // pair_mtp.cpp:116-118
           atomicExch(p.err_flag, 1);
         } else {
-          const double dx = p.x[3 * (size_t) j] - xi0, dy = p.x[3 * (size_t) j + 1] - xi1,
-                       dz = p.x[3 * (size_t) j + 2] - xi2;
-          in = !(dx * dx + dy * dy + dz * dz > p.cutsq);   // pair_mtp.cpp:123
+          dx = p.x[3 * (size_t) j] - xi0;
+          dy = p.x[3 * (size_t) j + 1] - xi1;
+          dz = p.x[3 * (size_t) j + 2] - xi2;
+          r2 = dx * dx + dy * dy + dz * dz;
+          in = !(r2 > p.cutsq);   // pair_mtp.cpp:123
         }
       }
       const unsigned long long m = __ballot(in);
-      if (in) w.cj[cnt + __popcll(m & ((1ull << lane) - 1ull))] = j;
-      cnt += __popcll(m);
+      if (in) {
+        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        w.cj[pos] = j;
+        if (pos < NT) {
+          const double r = sqrt(r2);
+          w.nbx[pos] = dx;
+          w.nby[pos] = dy;
+          w.nbz[pos] = dz;
+          w.nbr[pos] = r;
+          w.nbi[pos] = 1.0 / r;
+          w.nbj[pos] = j;
+          w.nbjt[pos] = jt;
+        }
+      }
+      cnt += __builtin_amdgcn_readfirstlane(__popcll(m));
+    }
+    {   // dummy neighbours pad tile 0 to a multiple of NG
+      const int pos = cnt + lane;
+      if (cnt < NT && lane < NG && pos < ((min(cnt, NT) + NG - 1) / NG) * NG) {
+        w.nbx[pos] = 0.0;
+        w.nby[pos] = 0.0;
+        w.nbz[pos] = 0.0;
+        w.nbr[pos] = p.rmax;
+        w.nbi[pos] = 1.0 / p.rmax;
+        w.nbj[pos] = i;
+        w.nbjt[pos] = itype;
+      }
     }
     wave_fence();
 
-    // ---- 2+3. tiles: tables, then basic moments in registers --------------------------------
+    // ---- 2+3. tiles: tables, then basic moments in registers ------------------------------
     double acc[KB];
 #pragma unroll
     for (int t = 0; t < KB; t++) acc[t] = 0.0;
-    const int ntiles = (cnt + p.NT - 1) / p.NT;
+    const int ntiles = (cnt + NT - 1) / NT;
     for (int tile = 0; tile < ntiles; tile++) {
-      const int t0 = tile * p.NT, nt = min(p.NT, cnt - t0);
-      build_tile(p, w, t0, nt, xi0, xi1, xi2, itype, lane);
-      for (int n = 0; n < nt; n++) {
-        const double *rec = w.tab + (size_t) n * p.stride;
+      const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
+      build_tile<PITCH>(p, bt, w, t0, cnt, ntp, tile > 0, xi0, xi1, xi2, i, itype, lane);
 #pragma unroll
-        for (int t = 0; t < KB; t++) acc[t] += rec[og[t]] * (rec[oxa[t]] * (rec[oyb[t]] * rec[ozc[t]]));
+      for (int m = 0; m < NPG; m++) {
+        if (m * NG < ntp) {
+#pragma unroll
+          for (int t = 0; t < KB; t++)
+            acc[t] += lds_ld(pg[t], m * NG) *
+                (lds_ld(px[t], PITCH + m * NG) * (lds_ld(py[t], PITCH + m * NG) * lds_ld(pz[t], PITCH + m * NG)));
+          // keep the scheduler from hoisting every tile read above the first FMA (register blow-up)
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       if (ntiles > 1) wave_fence();
     }
-    // moments + adjoints into LDS
+    // sum over the neighbour groups, then moments + adjoints into LDS
+#pragma unroll
+    for (int t = 0; t < KB; t++) {
+      if (NG >= 2) acc[t] += shfl_xor_f64(acc[t], KL);
+      if (NG >= 4) acc[t] += shfl_xor_f64(acc[t], 2 * KL);
+    }
     for (int m = p.B + lane; m < p.A; m += 64) w.M[m] = 0.0;
     for (int m = lane; m < p.A; m += 64) w.D[m] = 0.0;
+    if (q == 0) {
 #pragma unroll
-    for (int t = 0; t < KB; t++)
-      if (kval[t]) w.M[lane + 64 * t] = acc[t];
+      for (int t = 0; t < KB; t++)
+        if (kval[t]) w.M[kl + KL * t] = acc[t];
+    }
     wave_fence();
 
-    // ---- 4a. products, level by level (pair_mtp.cpp:196-201) ----------------------------------
+    // ---- 4a. products, level by level (pair_mtp.cpp:196-201) -----------------------------
+    // rows of one level never write an operand of the same level, so four rows per lane
+    // can be in flight before their ds_add_f64 issue
     for (int l = 0; l < p.nlevels; l++) {
-      for (int r = p.level_off[l] + lane; r < p.level_off[l + 1]; r += 64) {
-        const int4 row = p.rows[r];
-        lds_add(&w.M[row.w], (double) row.z * w.M[row.x] * w.M[row.y]);
+      const int end = bt.level[l + 1];
+      for (int r0 = bt.level[l] + lane; r0 < end; r0 += 256) {
+        MtpRow8 rw[4];
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int r = r0 + 64 * u;
+          MtpRow8 z = {0u, 0u};
+          rw[u] = r < end ? (rows_lds ? bt.rows[r] : p.rows[r]) : z;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = w.M[rw[u].lo & 0xffffu] * w.M[rw[u].lo >> 16];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (r0 + 64 * u < end)
+            lds_add(&w.M[rw[u].hi & 0xffffu], (double) ((int) rw[u].hi >> 16) * v[u]);
       }
       wave_fence();
     }
-    // ---- site energy (pair_mtp.cpp:204-212) ---------------------------------------------------
+    // ---- site energy (pair_mtp.cpp:204-212) ----------------------------------------------
     double e = 0.0;
-    for (int k = lane; k < p.S; k += 64) e += p.lin[k] * w.M[p.map[k]];
+    for (int k = lane; k < p.S; k += 64) e += bt.lin[k] * w.M[bt.map[k]];
     e = wave_sum(e) + p.species_coeffs[itype];
-    // ---- 4b. adjoints (pair_mtp.cpp:217-233) ---------------------------------------------------
-    for (int k = lane; k < p.nseed; k += 64) w.D[p.seed_idx[k]] = p.seed_val[k];
+    // ---- 4b. adjoints (pair_mtp.cpp:217-233) ----------------------------------------------
+    for (int k = lane; k < p.nseed; k += 64) w.D[bt.seed_idx[k]] = bt.seed_val[k];
     wave_fence();
     for (int l = p.nlevels - 1; l >= 0; l--) {
-      for (int r = p.level_off[l] + lane; r < p.level_off[l + 1]; r += 64) {
-        const int4 row = p.rows[r];
-        const double d3 = w.D[row.w] * (double) row.z;
-        lds_add(&w.D[row.y], d3 * w.M[row.x]);
-        lds_add(&w.D[row.x], d3 * w.M[row.y]);
+      const int end = bt.level[l + 1];
+      for (int r0 = bt.level[l] + lane; r0 < end; r0 += 256) {
+        MtpRow8 rw[4];
+        double d3[4], m0[4], m1[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int r = r0 + 64 * u;
+          MtpRow8 z = {0u, 0u};
+          rw[u] = r < end ? (rows_lds ? bt.rows[r] : p.rows[r]) : z;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          d3[u] = w.D[rw[u].hi & 0xffffu] * (double) ((int) rw[u].hi >> 16);
+          m0[u] = w.M[rw[u].lo & 0xffffu];
+          m1[u] = w.M[rw[u].lo >> 16];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (r0 + 64 * u < end) {
+            lds_add(&w.D[rw[u].lo >> 16], d3[u] * m0[u]);
+            lds_add(&w.D[rw[u].lo & 0xffffu], d3[u] * m1[u]);
+          }
       }
       wave_fence();
     }
 
     // ---- 5. forces ---------------------------------------------------------------------------
-    double Dk[KB];
-#pragma unroll
-    for (int t = 0; t < KB; t++) Dk[t] = kval[t] ? w.D[lane + 64 * t] : 0.0;
+    // adjoints of the basics, plain and times the chain-rule exponents, go into the (now
+    // free) moment region, zero-padded to KL*KB: DK/DA/DB/DC, read back with immediate offsets
+    constexpr int KP = KL * KB;
+    for (int k = lane; k < KP; k += 64) {
+      const bool ok = k < p.B;
+      const double d = ok ? w.D[k] : 0.0;
+      const int pk = ok ? bt.pack[k] : 0;
+      w.M[k] = d;
+      w.M[KP + k] = d * (double) ((pk >> 8) & 15);
+      w.M[2 * KP + k] = d * (double) ((pk >> 12) & 15);
+      w.M[3 * KP + k] = d * (double) ((pk >> 16) & 15);
+    }
+    unsigned pda = lds_addr(w.M + kl);
+    asm volatile("" : "+v"(pda));
+    wave_fence();
+    // the 16 lanes with kl < BATCH collect: force on i (3), virial (6)
     double fi0 = 0, fi1 = 0, fi2 = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
     for (int tile = 0; tile < ntiles; tile++) {
-      const int t0 = tile * p.NT, nt = min(p.NT, cnt - t0);
-      if (ntiles > 1) build_tile(p, w, t0, nt, xi0, xi1, xi2, itype, lane);
-      for (int g0 = 0; g0 < nt; g0 += 16) {
-        double part[64];
+      const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
+      if (ntiles > 1) build_tile<PITCH>(p, bt, w, t0, cnt, ntp, true, xi0, xi1, xi2, i, itype, lane);
 #pragma unroll
-        for (int nn = 0; nn < 16; nn++) {
-          double sr = 0, sx = 0, sy = 0, sz = 0;
-          if (g0 + nn < nt) {
-            const double *rec = w.tab + (size_t) (g0 + nn) * p.stride;
+      for (int b = 0; b < NBATCH; b++) {
+        if (b * BATCH * NG < ntp) {
+          double part[KL];
 #pragma unroll
-            for (int t = 0; t < KB; t++) {
-              const double g = rec[og[t]], gd = rec[ns + og[t]];
-              const double xa = rec[oxa[t]], yb = rec[oyb[t]], zc = rec[ozc[t]];
-              const double dxa = rec[oxa[t] + 3 * P], dyb = rec[oyb[t] + 3 * P], dzc = rec[ozc[t] + 3 * P];
-              const double yz = yb * zc, Dg = Dk[t] * g;
-              sr += (Dk[t] * gd) * (xa * yz);
-              sx += Dg * (dxa * yz);
-              sy += Dg * (xa * (dyb * zc));
-              sz += Dg * (xa * (yb * dzc));
+          for (int u = 0; u < KL; u++) part[u] = 0.0;
+          // stale columns beyond ntp only feed their own (discarded) slots of `part`
+#pragma unroll
+          for (int t = 0; t < KB; t++) {
+            const double Dk = lds_ld(pda, KL * t), Da = lds_ld(pda, KP + KL * t);
+            const double Db = lds_ld(pda, 2 * KP + KL * t), Dc = lds_ld(pda, 3 * KP + KL * t);
+#pragma unroll
+            for (int mm = 0; mm < BATCH; mm++) {
+              const int o = (b * BATCH + mm) * NG;   // column offset of this lane's neighbour
+              const double g = lds_ld(pg[t], o), gd = lds_ld(pg[t], PITCH + o);
+              const double xm = lds_ld(px[t], o), xa = lds_ld(px[t], PITCH + o);
+              const double ym = lds_ld(py[t], o), yb = lds_ld(py[t], PITCH + o);
+              const double zm = lds_ld(pz[t], o), zc = lds_ld(pz[t], PITCH + o);
+              const double yz = yb * zc, xz = xa * zc, xy = xa * yb;
+              part[4 * mm + 0] += (Dk * gd) * (xa * yz);
+              part[4 * mm + 1] += (Da * g) * (xm * yz);
+              part[4 * mm + 2] += (Db * g) * (ym * xz);
+              part[4 * mm + 3] += (Dc * g) * (zm * xy);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one basic's reads in flight at a time
+          }
+          Butterfly<KL>::run(part, lane);
+          w.red[lane] = part[0];   // lane (q, kl): value kl of group q
+          wave_fence();
+          const int n = q + NG * (b * BATCH + kl);
+          if (kl < BATCH && n < nt) {
+            const double *rq = w.red + q * KL + 4 * kl;
+            const double sr = rq[0] * w.nbi[n];
+            const double rx = w.nbx[n], ry = w.nby[n], rz = w.nbz[n];
+            const double Fx = sr * rx + rq[1];
+            const double Fy = sr * ry + rq[2];
+            const double Fz = sr * rz + rq[3];
+            const size_t j = (size_t) w.nbj[n];
+            unsafeAtomicAdd(&p.f[3 * j + 0], -Fx);   // pair_mtp.cpp:252-254
+            unsafeAtomicAdd(&p.f[3 * j + 1], -Fy);
+            unsafeAtomicAdd(&p.f[3 * j + 2], -Fz);
+            fi0 += Fx;
+            fi1 += Fy;
+            fi2 += Fz;
+            if (p.vflag) {   // pair_mtp.cpp:257-277
+              v0 -= Fx * rx;
+              v1 -= Fy * ry;
+              v2 -= Fz * rz;
+              v3 -= (Fx * ry + Fy * rx) * 0.5;
+              v4 -= (Fx * rz + Fz * rx) * 0.5;
+              v5 -= (Fy * rz + Fz * ry) * 0.5;
             }
           }
-          part[4 * nn + 0] = sr;
-          part[4 * nn + 1] = sx;
-          part[4 * nn + 2] = sy;
-          part[4 * nn + 3] = sz;
+          wave_fence();
         }
-        Butterfly<64>::run(part, lane);
-        w.red[lane] = part[0];
-        wave_fence();
-        if (lane < 16 && g0 + lane < nt) {
-          const int n = g0 + lane;
-          const double sr = w.red[4 * lane] * w.nbi[n];
-          const double rx = w.nbx[n], ry = w.nby[n], rz = w.nbz[n];
-          const double Fx = sr * rx + w.red[4 * lane + 1];
-          const double Fy = sr * ry + w.red[4 * lane + 2];
-          const double Fz = sr * rz + w.red[4 * lane + 3];
-          const size_t j = (size_t) w.nbj[n];
-          unsafeAtomicAdd(&p.f[3 * j + 0], -Fx);   // pair_mtp.cpp:252-254
-          unsafeAtomicAdd(&p.f[3 * j + 1], -Fy);
-          unsafeAtomicAdd(&p.f[3 * j + 2], -Fz);
-          fi0 += Fx;
-          fi1 += Fy;
-          fi2 += Fz;
-          if (p.vflag) {   // pair_mtp.cpp:257-277
-            v0 -= Fx * rx;
-            v1 -= Fy * ry;
-            v2 -= Fz * rz;
-            v3 -= (Fx * ry + Fy * rx) * 0.5;
-            v4 -= (Fx * rz + Fz * rx) * 0.5;
-            v5 -= (Fy * rz + Fz * ry) * 0.5;
-          }
-        }
-        wave_fence();
       }
     }
-    // per-atom totals: lanes 0..15 hold partial sums
-    fi0 = wave_sum(fi0);
-    fi1 = wave_sum(fi1);
-    fi2 = wave_sum(fi2);
-    if (p.vflag) {
-      v0 = wave_sum(v0);
-      v1 = wave_sum(v1);
-      v2 = wave_sum(v2);
-      v3 = wave_sum(v3);
-      v4 = wave_sum(v4);
-      v5 = wave_sum(v5);
+    // ---- per-atom totals: 9 values x 16 lanes through LDS, lane v sums value v -------------
+    if (kl < BATCH) {
+      const int li = q * BATCH + kl;   // 0..15
+      w.red[0 * 16 + li] = fi0;
+      w.red[1 * 16 + li] = fi1;
+      w.red[2 * 16 + li] = fi2;
+      w.red[3 * 16 + li] = v0;
+      w.red[4 * 16 + li] = v1;
+      w.red[5 * 16 + li] = v2;
+      w.red[6 * 16 + li] = v3;
+      w.red[7 * 16 + li] = v4;
+      w.red[8 * 16 + li] = v5;
     }
-    if (lane == 0) {
-      unsafeAtomicAdd(&p.f[3 * (size_t) i + 0], fi0);   // pair_mtp.cpp:248-250
-      unsafeAtomicAdd(&p.f[3 * (size_t) i + 1], fi1);
-      unsafeAtomicAdd(&p.f[3 * (size_t) i + 2], fi2);
+    wave_fence();
+    if (lane < 9) {
+      const double *r = w.red + 16 * lane;
+      double s = 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) s += (r[u] + r[u + 1]) + (r[u + 2] + r[u + 3]);
+      if (lane < 3) {
+        unsafeAtomicAdd(&p.f[3 * (size_t) i + lane], s);   // pair_mtp.cpp:248-250
+      } else if (p.vflag) {
+        tally += s;
+        if ((p.vflag & 4) && p.vatom) p.vatom[6 * (size_t) i + (lane - 3)] += s;
+      }
+    }
+    if (lane == 9) {
       if ((p.eflag & 2) && p.eatom) p.eatom[i] = e;
-      if (p.eflag & 1) ev_acc[0] += e;
-      if (p.vflag) {
-        ev_acc[1] += v0;
-        ev_acc[2] += v1;
-        ev_acc[3] += v2;
-        ev_acc[4] += v3;
-        ev_acc[5] += v4;
-        ev_acc[6] += v5;
-        if ((p.vflag & 4) && p.vatom) {
-          double *va = p.vatom + 6 * (size_t) i;
-          va[0] += v0;
-          va[1] += v1;
-          va[2] += v2;
-          va[3] += v3;
-          va[4] += v4;
-          va[5] += v5;
-        }
-      }
+      if (p.eflag & 1) tally += e;
     }
     wave_fence();
   }
-  if (lane == 0 && ((p.eflag & 1) || p.vflag)) {
+  if (lane >= 3 && lane <= 9 && tally != 0.0) {
     double *slot = p.ev_slots + 8 * (size_t) ((blockIdx.x * wpb + wave) % MTP_EV_SLOTS);
-#pragma unroll
-    for (int q = 0; q < 7; q++)
-      if (ev_acc[q] != 0.0) unsafeAtomicAdd(&slot[q], ev_acc[q]);
+    unsafeAtomicAdd(&slot[lane == 9 ? 0 : lane - 2], tally);
   }
 }
 
@@ -400,35 +548,71 @@ __global__ void mtp_ev_finish(double *ev_slots, double *ev)
   if (threadIdx.x == 0) ev[q] += s;
 }
 
-}   // namespace
-
-template <int KB> static hipError_t launch_kb(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
+template <int KL, int KB, int PITCH>
+hipError_t launch_one(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
 {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mtp_wave_kernel<KB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mtp_wave_kernel<KL, KB, PITCH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(mtp_wave_kernel<KB>, dim3(grid), dim3(64 * wpb), lds, st, p);
+  hipLaunchKernelGGL((mtp_wave_kernel<KL, KB, PITCH>), dim3(grid), dim3(64 * wpb), lds, st, p);
   return hipGetLastError();
+}
+
+template <int KL, int KB> hipError_t launch_pitch(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
+{
+  // only the 32-neighbour tile (pitch 34) is instantiated: hipcc 7.2 rejects the pitch-18 and
+  // KB = 1 shapes with a machine-verifier error ("Operand has incorrect register class")
+  return launch_one<KL, KB, 34>(p, grid, wpb, lds, st);
+}
+
+}   // namespace
+
+// Supported (KL, KB) shapes; mtp_pick_shape() is the single source of truth for the host.
+int mtp_pick_shape(int B, int *KL, int *KB)
+{
+  static const int kb16[] = {2, 3, 5, 7, 9, 10}, kbw[] = {6, 7, 8, 10};
+  for (int v : kb16)
+    if (B <= 16 * v) {
+      *KL = 16;
+      *KB = v;
+      return 0;
+    }
+  for (int kl : {32, 64})
+    for (int v : kbw)
+      if (B <= kl * v) {
+        *KL = kl;
+        *KB = v;
+        return 0;
+      }
+  return -1;
 }
 
 hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
 {
-  const int kb = (p.B + 63) / 64;
-  switch (kb) {
-    case 1: return launch_kb<1>(p, grid, wpb, lds, st);
-    case 2: return launch_kb<2>(p, grid, wpb, lds, st);
-    case 3: return launch_kb<3>(p, grid, wpb, lds, st);
-    case 4: return launch_kb<4>(p, grid, wpb, lds, st);
-    case 5: return launch_kb<5>(p, grid, wpb, lds, st);
-    case 6: return launch_kb<6>(p, grid, wpb, lds, st);
-    case 7: return launch_kb<7>(p, grid, wpb, lds, st);
-    case 8: return launch_kb<8>(p, grid, wpb, lds, st);
-    default: return hipErrorInvalidValue;
-  }
+  int KL = 0, KB = 0;
+  if (mtp_pick_shape(p.B, &KL, &KB) != 0 || p.NT != 32) return hipErrorInvalidValue;
+#define MTP_CASE(kl, kb) \
+  if (KL == kl && KB == kb) return launch_pitch<kl, kb>(p, grid, wpb, lds, st);
+  MTP_CASE(16, 2)
+  MTP_CASE(16, 3)
+  MTP_CASE(16, 5)
+  MTP_CASE(16, 7)
+  MTP_CASE(16, 9)
+  MTP_CASE(16, 10)
+  MTP_CASE(32, 6)
+  MTP_CASE(32, 7)
+  MTP_CASE(32, 8)
+  MTP_CASE(32, 10)
+  MTP_CASE(64, 6)
+  MTP_CASE(64, 7)
+  MTP_CASE(64, 8)
+  MTP_CASE(64, 10)
+#undef MTP_CASE
+  return hipErrorInvalidValue;
 }
 
 hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st)

@@ -1,0 +1,29 @@
+#!/bin/bash
+# PMC counter passes for the dominant kernel (separate rocprofv3 runs, kernel-trace only)
+OUT=gpurun_out/${1:-pmc}
+mkdir -p $OUT
+export TMPDIR=/tmp
+python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
+run() {
+  name=$1; shift
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/$name.json 2> $OUT/$name.err
+  echo "$name rc=$?"
+}
+run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
+run sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM
+run sq3 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_FLAT SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT
+run tcc1 FETCH_SIZE
+run tcc2 WRITE_SIZE
+run tcc3 TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum
+python - <<PY
+import csv, glob, collections
+for name in ["sq1","sq2","sq3","tcc1","tcc2","tcc3"]:
+    files = glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True)
+    acc = collections.defaultdict(list)
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if "mtp_wave_kernel" in row.get("Kernel_Name",""):
+                acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k,v in acc.items():
+        print("%s %-28s mean per launch %.6g  (n=%d)" % (name, k, sum(v)/len(v), len(v)))
+PY
