@@ -98,15 +98,15 @@ void mtp_context::plan()
 {
   const mtp_potential &p = *pot;
   const int A = p.alpha_moment_count, P = p.max_alpha_index_basic;
-  const int tab_rows = 2 * p.slot_count + 3 * (P + 1);
+  const int tab_rows = 2 * p.slot_count + 3 * P;
   int KL = 16, KB = 1;
   (void) mtp_pick_shape(p.alpha_index_basic_count, &KL, &KB);
-  const int m_doubles = std::max(A, 4 * KL * KB);
+  const int m_doubles = std::max(std::max(A, 4 * KL * KB), 144);
   const int cap = std::max(64, (max_numneigh + 63) / 64 * 64);
   const size_t LDS = 160 * 1024;
   const size_t blob = (size_t) base.blob_bytes;
   auto wave_bytes = [&](int nt) {
-    size_t dbl = (size_t) A + m_doubles + (size_t) tab_rows * (nt + 2) + 5 * (size_t) nt + 144;
+    size_t dbl = (size_t) A + m_doubles + (size_t) tab_rows * (nt + 2) + 5 * (size_t) nt + 64;
     size_t ints = (size_t) 2 * nt + cap;
     return (dbl * 8 + ints * 4 + 15) / 16 * 16;
   };

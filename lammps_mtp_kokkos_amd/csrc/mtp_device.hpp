@@ -53,7 +53,7 @@ struct MtpDevParams {
   int eflag, vflag, grade_flag;
   // launch geometry
   int NT;                  // neighbours per LDS tile: 32 or 16 (table row pitch = NT + 2 doubles)
-  int tab_rows;            // table rows = 2*nslot + 3*(P+1)
+  int tab_rows;            // table rows = 2*nslot + 3*P
   int cj_cap;              // capacity of the compacted id list
   int wave_doubles;        // LDS doubles per wavefront
   int m_doubles;           // doubles of the moment region = max(A, 4*KL*KB)

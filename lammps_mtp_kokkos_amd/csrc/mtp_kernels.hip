@@ -62,13 +62,13 @@ __device__ __forceinline__ void lds_add(double *p, double v)
 // LDS read at (32-bit LDS byte address + compile-time byte offset): the offset lands in the
 // ds_read immediate field, so inner loops spend no VALU on addressing.
 typedef __attribute__((address_space(3))) const double lds_cdouble;
-__device__ __forceinline__ unsigned lds_addr(const double *p)
-{
-  return (unsigned) (size_t) (lds_cdouble *) p;
-}
+// (no generic -> LDS pointer casts: hipcc 7.2 miscompiles their null check on gfx950; LDS byte
+// addresses are formed as the LDS address of the dynamic array + an offset instead)
+// volatile: hipcc otherwise fuses neighbouring reads into ds_read2_b64, which moves 16 B per lane in
+// 8 LDS cycles where two ds_read_b64 take 4 (MI355X_MICROARCH.md, LDS table)
 __device__ __forceinline__ double lds_ld(unsigned base, int off_doubles)   // off: constant after unrolling
 {
-  return *(lds_cdouble *) (size_t) (base + 8u * (unsigned) off_doubles);
+  return *(volatile lds_cdouble *) (size_t) (base + 8u * (unsigned) off_doubles);
 }
 
 // Butterfly transpose-reduce over the lane bits below N: every lane enters with N partial
@@ -102,9 +102,12 @@ template <int PITCH> struct WaveLds {
   static constexpr int NT = PITCH - 2;
   double *M, *D, *tab, *nbx, *nby, *nbz, *nbr, *nbi, *red;
   int *nbj, *nbjt, *cj;
-  __device__ __forceinline__ WaveLds(double *base, const MtpDevParams &p)
+  unsigned m_addr;   // LDS byte address of M
+  __device__ __forceinline__ unsigned addr(const double *ptr) const { return m_addr + 8u * (unsigned) (ptr - M); }
+  __device__ __forceinline__ WaveLds(double *base, unsigned base_addr, const MtpDevParams &p)
   {
     M = base;
+    m_addr = base_addr;
     D = M + p.m_doubles;   // M region also hosts the exponent-weighted adjoints in phase 5
     tab = D + p.A;
     nbx = tab + (size_t) p.tab_rows * PITCH;
@@ -112,8 +115,8 @@ template <int PITCH> struct WaveLds {
     nbz = nby + NT;
     nbr = nbz + NT;
     nbi = nbr + NT;
-    red = nbi + NT;   // 144 doubles
-    nbj = reinterpret_cast<int *>(red + 144);
+    red = nbi + NT;   // 64 doubles
+    nbj = reinterpret_cast<int *>(red + 64);
     nbjt = nbj + NT;
     cj = nbjt + NT;
   }
@@ -181,8 +184,8 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
       const int s = sl[nu];
       const double g = val * rp;
       if (s >= 0) {
-        col[(2 * s) * PITCH] = g;                                // f_mu / r^nu
-        col[(2 * s + 1) * PITCH] = der * rp - nu * g * inv;      // d/dr (f_mu / r^nu)
+        col[s * PITCH] = g;                                       // f_mu / r^nu
+        col[(p.nslot + s) * PITCH] = der * rp - nu * g * inv;     // d/dr (f_mu / r^nu)
       }
       rp *= inv;
     }
@@ -190,8 +193,8 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
   for (int idx = lane; idx < ntp * 3; idx += 64) {
     const int n = __float2int_rz((idx + 0.5f) * (1.0f / 3.0f)), ax = idx - 3 * n;
     const double u = ax == 0 ? w.nbx[n] : (ax == 1 ? w.nby[n] : w.nbz[n]);
-    // rows of one axis: [0] = 0 ("u^-1" partner of the factor a = 0), [1 + q] = u^q
-    double *col = w.tab + (size_t) (2 * p.nslot + ax * (P + 1) + 1) * PITCH + n;
+    // rows of one axis: [q] = u^q
+    double *col = w.tab + (size_t) (2 * p.nslot + ax * P) * PITCH + n;
     double cur = 1.0;
     col[0] = 1.0;
     for (int q = 1; q < P; q++) {
@@ -200,6 +203,66 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
     }
   }
   wave_fence();
+}
+
+// Phase 4a: M[a3] += mult * M[a0] * M[a1], one dependency level at a time.  Rows of one level
+// never write an operand of the same level, so four rows per lane are in flight before their
+// ds_add_f64 issue.  (Two call sites, LDS-resident and HBM-resident rows: a select between the two
+// pointers would go through a generic pointer, which hipcc 7.2 miscompiles on gfx950.)
+__device__ __forceinline__ void products_forward(const MtpRow8 *rows, const int *level, int nlevels, double *M,
+                                                 int lane)
+{
+  for (int l = 0; l < nlevels; l++) {
+    const int end = level[l + 1];
+    for (int r0 = level[l] + lane; r0 < end; r0 += 256) {
+      MtpRow8 rw[4];
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int r = r0 + 64 * u;
+        MtpRow8 z = {0u, 0u};
+        rw[u] = r < end ? rows[r] : z;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = M[rw[u].lo & 0xffffu] * M[rw[u].lo >> 16];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (r0 + 64 * u < end) lds_add(&M[rw[u].hi & 0xffffu], (double) ((int) rw[u].hi >> 16) * v[u]);
+    }
+    wave_fence();
+  }
+}
+
+// Phase 4b: D[a1] += D[a3] mult M[a0]; D[a0] += D[a3] mult M[a1], levels in reverse.
+__device__ __forceinline__ void products_backward(const MtpRow8 *rows, const int *level, int nlevels,
+                                                  const double *M, double *D, int lane)
+{
+  for (int l = nlevels - 1; l >= 0; l--) {
+    const int end = level[l + 1];
+    for (int r0 = level[l] + lane; r0 < end; r0 += 256) {
+      MtpRow8 rw[4];
+      double d3[4], m0[4], m1[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int r = r0 + 64 * u;
+        MtpRow8 z = {0u, 0u};
+        rw[u] = r < end ? rows[r] : z;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        d3[u] = D[rw[u].hi & 0xffffu] * (double) ((int) rw[u].hi >> 16);
+        m0[u] = M[rw[u].lo & 0xffffu];
+        m1[u] = M[rw[u].lo >> 16];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (r0 + 64 * u < end) {
+          lds_add(&D[rw[u].lo >> 16], d3[u] * m0[u]);
+          lds_add(&D[rw[u].lo & 0xffffu], d3[u] * m1[u]);
+        }
+    }
+    wave_fence();
+  }
 }
 
 template <int KL, int KB, int PITCH>
@@ -235,18 +298,14 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wpb = blockDim.x >> 6;
   const int kl = lane & (KL - 1), q = lane / KL;
-  const WaveLds<PITCH> w(lds + (p.blob_bytes >> 3) + (size_t) wave * p.wave_doubles, p);
+  const unsigned wave_off = (p.blob_bytes >> 3) + wave * p.wave_doubles;   // doubles
+  const unsigned lds0 = (unsigned) (size_t) (lds_cdouble *) lds;            // static cast of the array itself
+  const WaveLds<PITCH> w(lds + wave_off, lds0 + 8u * wave_off, p);
   const int ns = p.nslot, P = p.P;
-
-  // the three "power -1" rows stay zero for the whole launch
-  for (int c = lane; c < 3 * NT; c += 64) {
-    const int ax = c / NT, n = c - ax * NT;
-    w.tab[(size_t) (2 * ns + ax * (P + 1)) * PITCH + n] = 0.0;
-  }
 
   // per-lane descriptors of the basics this lane owns (k = kl + KL t): LDS row bases for
   // this lane's neighbour column q; the partner row (dg, next power) is +PITCH
-  unsigned pg[KB], px[KB], py[KB], pz[KB];   // LDS byte addresses
+  unsigned pg[KB], pd[KB], px[KB], py[KB], pz[KB];   // LDS byte addresses
   bool kval[KB];
 #pragma unroll
   for (int t = 0; t < KB; t++) {
@@ -254,13 +313,17 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     kval[t] = k < p.B;
     const int pk = kval[t] ? bt.pack[k] : 0;
     const int a = (pk >> 8) & 15, b = (pk >> 12) & 15, c = (pk >> 16) & 15;
-    pg[t] = lds_addr(w.tab + (size_t) (2 * (pk & 255)) * PITCH + q);
-    px[t] = lds_addr(w.tab + (size_t) (2 * ns + a) * PITCH + q);         // row of x^(a-1)
-    py[t] = lds_addr(w.tab + (size_t) (2 * ns + (P + 1) + b) * PITCH + q);
-    pz[t] = lds_addr(w.tab + (size_t) (2 * ns + 2 * (P + 1) + c) * PITCH + q);
+    // rows: g at slot, dg at ns + slot (bank spread 2*row + column: conflict-free over 16 slots);
+    // px/py/pz point at the row BELOW u^a: u^(a-1), or for a = 0 some finite value that only
+    // ever meets the factor D*a = 0; the power itself is +PITCH
+    pg[t] = w.addr(w.tab + (size_t) (pk & 255) * PITCH + q);
+    pd[t] = w.addr(w.tab + (size_t) (ns + (pk & 255)) * PITCH + q);
+    px[t] = w.addr(w.tab + (size_t) (2 * ns + a - 1) * PITCH + q);
+    py[t] = w.addr(w.tab + (size_t) (2 * ns + P + b - 1) * PITCH + q);
+    pz[t] = w.addr(w.tab + (size_t) (2 * ns + 2 * P + c - 1) * PITCH + q);
     // one finished address per register: stops the optimiser from re-splitting them into
     // base + row offset (which costs a v_add per LDS read in the inner loops)
-    asm volatile("" : "+v"(pg[t]), "+v"(px[t]), "+v"(py[t]), "+v"(pz[t]));
+    asm volatile("" : "+v"(pg[t]), "+v"(pd[t]), "+v"(px[t]), "+v"(py[t]), "+v"(pz[t]));
   }
 
   double tally = 0.0;   // lane 9: energy, lanes 3..8: virial components of this wave's atoms
@@ -363,28 +426,8 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     wave_fence();
 
     // ---- 4a. products, level by level (pair_mtp.cpp:196-201) -----------------------------
-    // rows of one level never write an operand of the same level, so four rows per lane
-    // can be in flight before their ds_add_f64 issue
-    for (int l = 0; l < p.nlevels; l++) {
-      const int end = bt.level[l + 1];
-      for (int r0 = bt.level[l] + lane; r0 < end; r0 += 256) {
-        MtpRow8 rw[4];
-        double v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int r = r0 + 64 * u;
-          MtpRow8 z = {0u, 0u};
-          rw[u] = r < end ? (rows_lds ? bt.rows[r] : p.rows[r]) : z;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = w.M[rw[u].lo & 0xffffu] * w.M[rw[u].lo >> 16];
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (r0 + 64 * u < end)
-            lds_add(&w.M[rw[u].hi & 0xffffu], (double) ((int) rw[u].hi >> 16) * v[u]);
-      }
-      wave_fence();
-    }
+    if (rows_lds) products_forward(bt.rows, bt.level, p.nlevels, w.M, lane);
+    else products_forward(p.rows, bt.level, p.nlevels, w.M, lane);
     // ---- site energy (pair_mtp.cpp:204-212) ----------------------------------------------
     double e = 0.0;
     for (int k = lane; k < p.S; k += 64) e += bt.lin[k] * w.M[bt.map[k]];
@@ -392,32 +435,8 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     // ---- 4b. adjoints (pair_mtp.cpp:217-233) ----------------------------------------------
     for (int k = lane; k < p.nseed; k += 64) w.D[bt.seed_idx[k]] = bt.seed_val[k];
     wave_fence();
-    for (int l = p.nlevels - 1; l >= 0; l--) {
-      const int end = bt.level[l + 1];
-      for (int r0 = bt.level[l] + lane; r0 < end; r0 += 256) {
-        MtpRow8 rw[4];
-        double d3[4], m0[4], m1[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int r = r0 + 64 * u;
-          MtpRow8 z = {0u, 0u};
-          rw[u] = r < end ? (rows_lds ? bt.rows[r] : p.rows[r]) : z;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          d3[u] = w.D[rw[u].hi & 0xffffu] * (double) ((int) rw[u].hi >> 16);
-          m0[u] = w.M[rw[u].lo & 0xffffu];
-          m1[u] = w.M[rw[u].lo >> 16];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (r0 + 64 * u < end) {
-            lds_add(&w.D[rw[u].lo >> 16], d3[u] * m0[u]);
-            lds_add(&w.D[rw[u].lo & 0xffffu], d3[u] * m1[u]);
-          }
-      }
-      wave_fence();
-    }
+    if (rows_lds) products_backward(bt.rows, bt.level, p.nlevels, w.M, w.D, lane);
+    else products_backward(p.rows, bt.level, p.nlevels, w.M, w.D, lane);
 
     // ---- 5. forces ---------------------------------------------------------------------------
     // adjoints of the basics, plain and times the chain-rule exponents, go into the (now
@@ -432,7 +451,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
       w.M[2 * KP + k] = d * (double) ((pk >> 12) & 15);
       w.M[3 * KP + k] = d * (double) ((pk >> 16) & 15);
     }
-    unsigned pda = lds_addr(w.M + kl);
+    unsigned pda = w.addr(w.M + kl);
     asm volatile("" : "+v"(pda));
     wave_fence();
     // the 16 lanes with kl < BATCH collect: force on i (3), virial (6)
@@ -454,7 +473,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
 #pragma unroll
             for (int mm = 0; mm < BATCH; mm++) {
               const int o = (b * BATCH + mm) * NG;   // column offset of this lane's neighbour
-              const double g = lds_ld(pg[t], o), gd = lds_ld(pg[t], PITCH + o);
+              const double g = lds_ld(pg[t], o), gd = lds_ld(pd[t], o);
               const double xm = lds_ld(px[t], o), xa = lds_ld(px[t], PITCH + o);
               const double ym = lds_ld(py[t], o), yb = lds_ld(py[t], PITCH + o);
               const double zm = lds_ld(pz[t], o), zc = lds_ld(pz[t], PITCH + o);
@@ -500,19 +519,20 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     // ---- per-atom totals: 9 values x 16 lanes through LDS, lane v sums value v -------------
     if (kl < BATCH) {
       const int li = q * BATCH + kl;   // 0..15
-      w.red[0 * 16 + li] = fi0;
-      w.red[1 * 16 + li] = fi1;
-      w.red[2 * 16 + li] = fi2;
-      w.red[3 * 16 + li] = v0;
-      w.red[4 * 16 + li] = v1;
-      w.red[5 * 16 + li] = v2;
-      w.red[6 * 16 + li] = v3;
-      w.red[7 * 16 + li] = v4;
-      w.red[8 * 16 + li] = v5;
+      double *fin = w.M;               // the moment region is free again (m_doubles >= 144)
+      fin[0 * 16 + li] = fi0;
+      fin[1 * 16 + li] = fi1;
+      fin[2 * 16 + li] = fi2;
+      fin[3 * 16 + li] = v0;
+      fin[4 * 16 + li] = v1;
+      fin[5 * 16 + li] = v2;
+      fin[6 * 16 + li] = v3;
+      fin[7 * 16 + li] = v4;
+      fin[8 * 16 + li] = v5;
     }
     wave_fence();
     if (lane < 9) {
-      const double *r = w.red + 16 * lane;
+      const double *r = w.M + 16 * lane;
       double s = 0.0;
 #pragma unroll
       for (int u = 0; u < 16; u += 4) s += (r[u] + r[u + 1]) + (r[u + 2] + r[u + 3]);
