@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmtp_mi355x.so")
+LIB_PATH = os.environ.get("MTP_LIB", os.path.join(_HERE, "libmtp_mi355x.so"))   # MTP_LIB: diagnostic builds
 
 MTP_OK = 0
 ERR_NAMES = {-2: "IO", -3: "EOF", -4: "FORMAT", -5: "PARSE", -6: "UNSUPPORTED", -7: "TABLE",

@@ -79,6 +79,7 @@ struct mtp_context {
   // workspaces
   DevBuf<double> d_ev_slots, d_ev, d_maxg;
   DevBuf<int> d_err;
+  DevBuf<unsigned long long> d_stamps;
   // launch geometry
   int NT = 32, wpb = 4, grid = 0, wave_doubles = 0;
   size_t lds_bytes = 0;
@@ -315,6 +316,8 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     c->d_maxg.reserve(1);
     c->d_err.reserve(1);
     HIP_CHECK(hipMemsetAsync(c->d_err.ptr, 0, sizeof(int), st));
+    c->d_stamps.reserve(16);
+    HIP_CHECK(hipMemsetAsync(c->d_stamps.ptr, 0, 16 * sizeof(unsigned long long), st));
     HIP_CHECK(hipStreamSynchronize(st));
 
     MtpDevParams &b = c->base;
@@ -341,6 +344,7 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     b.inv_active = pot->has_selection ? c->d_inv_active.ptr : nullptr;
     b.ev_slots = c->d_ev_slots.ptr;
     b.err_flag = c->d_err.ptr;
+    b.stamps = c->d_stamps.ptr;
     int kl_ = 0, kb_ = 0;
     if (mtp_pick_shape(pot->alpha_index_basic_count, &kl_, &kb_) != 0) {
       copy_err("alpha_index_basic_count above 640 is not supported by this build", err, errlen);
@@ -604,6 +608,15 @@ int mtp_context_launch_info(const mtp_context *c, int32_t *lds_bytes_per_wave, i
   if (waves_per_block) *waves_per_block = c->wpb;
   if (grid_blocks) *grid_blocks = c->grid;
   if (neighbor_tile) *neighbor_tile = c->NT;
+  return MTP_OK;
+}
+
+// diagnostic builds only: read and clear the per-phase cycle sums (not part of the public ABI)
+int mtp_debug_read_stamps(mtp_context *c, unsigned long long *out16)
+{
+  if (!c || !out16) return MTP_ERR_ARG;
+  if (hipMemcpy(out16, c->d_stamps.ptr, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return MTP_ERR_DEVICE;
+  (void) hipMemset(c->d_stamps.ptr, 0, 16 * sizeof(unsigned long long));
   return MTP_OK;
 }
 

@@ -50,6 +50,7 @@ struct MtpDevParams {
   double *max_grade;       // [1] or null
   double *coeff_ders;      // [C] or null
   int *err_flag;
+  unsigned long long *stamps;   // [16] diagnostic build only (MTP_STAMPS), else unused
   int eflag, vflag, grade_flag;
   // launch geometry
   int NT;                  // neighbours per LDS tile: 32 or 16 (table row pitch = NT + 2 doubles)

@@ -35,6 +35,20 @@
 
 #define MTP_NEIGHMASK 0x1FFFFFFF   // LAMMPS NEIGHMASK (pair_mtp.cpp:114)
 
+// Diagnostic build only (make stamps): per-phase s_memtime sums per launch into p.stamps[16].
+// The shipped library is built without MTP_STAMPS and executes no stamp.
+#ifdef MTP_STAMPS
+#define STAMP(k)                                                         \
+  do {                                                                   \
+    const unsigned long long _t = __builtin_amdgcn_s_memtime();          \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                  \
+    st_acc[k] += _t - st_prev;                                           \
+    st_prev = _t;                                                        \
+  } while (0)
+#else
+#define STAMP(k) ((void) 0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ void wave_fence()
@@ -56,7 +70,11 @@ __device__ __forceinline__ double wave_sum(double v)
 
 __device__ __forceinline__ void lds_add(double *p, double v)
 {
+#ifdef MTP_EXP_NOATOM   // timing experiment only (wrong results): plain store instead of ds_add_f64
+  *(volatile double *) p = v;
+#else
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 }
 
 // LDS read at (32-bit LDS byte address + compile-time byte offset): the offset lands in the
@@ -218,11 +236,7 @@ __device__ __forceinline__ void products_forward(const MtpRow8 *rows, const int 
       MtpRow8 rw[4];
       double v[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int r = r0 + 64 * u;
-        MtpRow8 z = {0u, 0u};
-        rw[u] = r < end ? rows[r] : z;
-      }
+      for (int u = 0; u < 4; u++) rw[u] = rows[min(r0 + 64 * u, end - 1)];   // clamped: no pointer select
 #pragma unroll
       for (int u = 0; u < 4; u++) v[u] = M[rw[u].lo & 0xffffu] * M[rw[u].lo >> 16];
 #pragma unroll
@@ -243,11 +257,7 @@ __device__ __forceinline__ void products_backward(const MtpRow8 *rows, const int
       MtpRow8 rw[4];
       double d3[4], m0[4], m1[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int r = r0 + 64 * u;
-        MtpRow8 z = {0u, 0u};
-        rw[u] = r < end ? rows[r] : z;
-      }
+      for (int u = 0; u < 4; u++) rw[u] = rows[min(r0 + 64 * u, end - 1)];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         d3[u] = D[rw[u].hi & 0xffffu] * (double) ((int) rw[u].hi >> 16);
@@ -327,6 +337,10 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
   }
 
   double tally = 0.0;   // lane 9: energy, lanes 3..8: virial components of this wave's atoms
+#ifdef MTP_STAMPS
+  unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
 
   for (int ii = blockIdx.x * wpb + wave; ii < p.inum; ii += gridDim.x * wpb) {
     const int i = p.ilist[ii];
@@ -338,6 +352,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     const double xi0 = p.x[3 * (size_t) i], xi1 = p.x[3 * (size_t) i + 1], xi2 = p.x[3 * (size_t) i + 2];
     const int jbeg = p.first[ii], jnum = p.first[ii + 1] - jbeg;
 
+    STAMP(0);   // loop head: ilist/type/x/first loads issue
     // ---- 1. compaction (the first NT survivors go straight into the tile arrays) --------
     int cnt = 0;
     for (int c0 = 0; c0 < jnum; c0 += 64) {
@@ -389,6 +404,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     }
     wave_fence();
 
+    STAMP(1);   // compaction
     // ---- 2+3. tiles: tables, then basic moments in registers ------------------------------
     double acc[KB];
 #pragma unroll
@@ -397,6 +413,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     for (int tile = 0; tile < ntiles; tile++) {
       const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
       build_tile<PITCH>(p, bt, w, t0, cnt, ntp, tile > 0, xi0, xi1, xi2, i, itype, lane);
+      STAMP(2);   // tile tables
 #pragma unroll
       for (int m = 0; m < NPG; m++) {
         if (m * NG < ntp) {
@@ -404,12 +421,13 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
           for (int t = 0; t < KB; t++)
             acc[t] += lds_ld(pg[t], m * NG) *
                 (lds_ld(px[t], PITCH + m * NG) * (lds_ld(py[t], PITCH + m * NG) * lds_ld(pz[t], PITCH + m * NG)));
-          // keep the scheduler from hoisting every tile read above the first FMA (register blow-up)
+          // without this the scheduler hoists every tile read above the first FMA and spills
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       if (ntiles > 1) wave_fence();
     }
+    STAMP(3);   // basic moments
     // sum over the neighbour groups, then moments + adjoints into LDS
 #pragma unroll
     for (int t = 0; t < KB; t++) {
@@ -428,6 +446,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     // ---- 4a. products, level by level (pair_mtp.cpp:196-201) -----------------------------
     if (rows_lds) products_forward(bt.rows, bt.level, p.nlevels, w.M, lane);
     else products_forward(p.rows, bt.level, p.nlevels, w.M, lane);
+    STAMP(4);   // products forward
     // ---- site energy (pair_mtp.cpp:204-212) ----------------------------------------------
     double e = 0.0;
     for (int k = lane; k < p.S; k += 64) e += bt.lin[k] * w.M[bt.map[k]];
@@ -435,9 +454,11 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     // ---- 4b. adjoints (pair_mtp.cpp:217-233) ----------------------------------------------
     for (int k = lane; k < p.nseed; k += 64) w.D[bt.seed_idx[k]] = bt.seed_val[k];
     wave_fence();
+    STAMP(5);   // energy + seeds
     if (rows_lds) products_backward(bt.rows, bt.level, p.nlevels, w.M, w.D, lane);
     else products_backward(p.rows, bt.level, p.nlevels, w.M, w.D, lane);
 
+    STAMP(6);   // products backward
     // ---- 5. forces ---------------------------------------------------------------------------
     // adjoints of the basics, plain and times the chain-rule exponents, go into the (now
     // free) moment region, zero-padded to KL*KB: DK/DA/DB/DC, read back with immediate offsets
@@ -483,7 +504,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
               part[4 * mm + 2] += (Db * g) * (ym * xz);
               part[4 * mm + 3] += (Dc * g) * (zm * xy);
             }
-            __builtin_amdgcn_sched_barrier(0);   // one basic's reads in flight at a time
+            __builtin_amdgcn_sched_barrier(0);   // one basic's reads in flight at a time (register pressure)
           }
           Butterfly<KL>::run(part, lane);
           w.red[lane] = part[0];   // lane (q, kl): value kl of group q
@@ -516,6 +537,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
         }
       }
     }
+    STAMP(7);   // forces
     // ---- per-atom totals: 9 values x 16 lanes through LDS, lane v sums value v -------------
     if (kl < BATCH) {
       const int li = q * BATCH + kl;   // 0..15
@@ -548,7 +570,12 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
       if (p.eflag & 1) tally += e;
     }
     wave_fence();
+    STAMP(8);   // per-atom totals
   }
+#ifdef MTP_STAMPS
+  if (lane == 0 && p.stamps)
+    for (int k = 0; k < 10; k++) atomicAdd(p.stamps + k, st_acc[k]);
+#endif
   if (lane >= 3 && lane <= 9 && tally != 0.0) {
     double *slot = p.ev_slots + 8 * (size_t) ((blockIdx.x * wpb + wave) % MTP_EV_SLOTS);
     unsafeAtomicAdd(&slot[lane == 9 ? 0 : lane - 2], tally);
