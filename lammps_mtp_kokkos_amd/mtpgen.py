@@ -343,25 +343,31 @@ class _Lowerer:
         return self._comp_lookup(types, mat, U)({})
 
     def _product(self, ids):
+        """Scalar = product of scalar factors.  Every sub-multiset of the factors is itself a
+        basis function made earlier (fewer tensors, lower level), so any split costs exactly
+        one row; the split that halves the factor list keeps the dependency depth of the
+        times table logarithmic instead of linear in the number of factors."""
         ids = tuple(sorted(ids))
         if len(ids) == 1:
             return ids[0]
         if ids in self.prod_cache:
             return self.prod_cache[ids]
-        # peel one factor; prefer a split whose remainder already exists
-        choice = None
-        for k in range(len(ids)):
-            rest = ids[:k] + ids[k + 1:]
-            if len(rest) == 1 or rest in self.prod_cache:
-                choice = k
+        h = len(ids) // 2
+        best = None
+        # prefer a balanced split whose halves already exist; fall back to plain halves
+        for left in itertools.combinations(range(len(ids)), h):
+            a = tuple(ids[i] for i in left)
+            b = tuple(ids[i] for i in range(len(ids)) if i not in left)
+            have = (len(a) == 1 or a in self.prod_cache) + (len(b) == 1 or b in self.prod_cache)
+            if best is None or have > best[0]:
+                best = (have, a, b)
+            if have == 2:
                 break
-        if choice is None:
-            choice = len(ids) - 1
-        rest = ids[:choice] + ids[choice + 1:]
-        r = self._product(rest)
+        _, a, b = best
+        ra, rb = self._product(a), self._product(b)
         out = self.nmom
         self.nmom += 1
-        a0, a1 = sorted((r, ids[choice]))
+        a0, a1 = sorted((ra, rb))
         self.rows[(a0, a1, out)] = self.rows.get((a0, a1, out), 0) + 1
         self.prod_cache[ids] = out
         return out

@@ -41,11 +41,26 @@ def test_generator_sizes_match_survey_enumeration():
 
 
 def test_generator_level8_is_known_answer():
+    """Same basics, sizes and scalar order as the level-8 template of SURVEY.md App. A; the
+    rows agree except where the generator picks a shallower (balanced) product for M00^4, so
+    the two tables are compared as polynomials on random moments."""
     t = mtpgen.build_table(8)
     k = mtpgen.LEVEL8_KNOWN_ANSWER
     assert t.basic == k["basic"]
-    assert sorted(t.times) == sorted(k["times"])
-    assert t.mapping == k["mapping"] and t.nmoments == k["nmoments"]
+    assert t.mapping == k["mapping"] and t.nmoments == k["nmoments"] and len(t.times) == len(k["times"])
+    assert len(set(t.times) ^ set(k["times"])) <= 2
+    rng = np.random.default_rng(0)
+
+    def scalars(times):
+        m = np.zeros(k["nmoments"])
+        m[:11] = rng_vals
+        for a0, a1, mu, a3 in times:
+            m[a3] += mu * m[a0] * m[a1]
+        return m[k["mapping"]]
+
+    for _ in range(3):
+        rng_vals = rng.uniform(-1, 1, 11)
+        np.testing.assert_allclose(scalars(t.times), scalars(k["times"]), rtol=1e-14)
 
 
 def test_parser_roundtrip(tmp_path):
