@@ -64,7 +64,7 @@ struct mtp_context {
   int variant = MTP_VARIANT_AUTO;
   int num_cus = 256;
   // potential tables
-  DevBuf<double> d_species, d_inv_active;
+  DevBuf<double> d_species;
   DevBuf<MtpRow8> d_rows;
   DevBuf<unsigned char> d_blob;
   // neighbour list
@@ -81,8 +81,12 @@ struct mtp_context {
   DevBuf<int> d_err;
   DevBuf<unsigned long long> d_stamps;
   // launch geometry
-  int NT = 32, wpb = 4, grid = 0, wave_doubles = 0;
-  size_t lds_bytes = 0;
+  struct LaunchPlan {
+    int wpb = 1, grid = 1, wave_doubles = 0, tab_rows = 0, g_doubles = 0, m_doubles = 0;
+    size_t lds_bytes = 0;
+  } lp[2];   // [0] force calls, [1] grade calls
+  DevBuf<double> d_cvec, d_ainv_pad;
+  int cpad = 0;
   // timing
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -93,72 +97,60 @@ struct mtp_context {
   void plan();
 };
 
-// Choose the neighbour tile and the workgroup shape from the LDS budget (160 KiB / CU):
-// every workgroup carries one copy of the table blob plus one private region per wavefront.
+// Choose the workgroup shape from the LDS budget (160 KiB / CU): every workgroup carries one copy
+// of the table blob plus one private region per wavefront.  Grade calls need extra table rows
+// (r^-nu, Q_ri) and scratch, so they get their own plan.
 void mtp_context::plan()
 {
   const mtp_potential &p = *pot;
   const int A = p.alpha_moment_count, P = p.max_alpha_index_basic;
-  const int tab_rows = 2 * p.slot_count + 3 * P;
   int KL = 16, KB = 1;
   (void) mtp_pick_shape(p.alpha_index_basic_count, &KL, &KB);
-  const int m_doubles = std::max(std::max(A, 4 * KL * KB), 144);
   const int cap = std::max(64, (max_numneigh + 63) / 64 * 64);
   const size_t LDS = 160 * 1024;
   const size_t blob = (size_t) base.blob_bytes;
-  auto wave_bytes = [&](int nt) {
-    size_t dbl = (size_t) A + m_doubles + (size_t) tab_rows * (nt + 2) + 5 * (size_t) nt + 64;
-    size_t ints = (size_t) 2 * nt + cap;
-    return (dbl * 8 + ints * 4 + 15) / 16 * 16;
-  };
-  // waves per CU for a (tile, waves-per-workgroup) choice; registers allow 8 (2 per SIMD)
-  auto waves_per_cu = [&](int nt, int w) {
-    size_t blk = blob + w * wave_bytes(nt);
-    if (blk > LDS) return 0;
-    return std::min<int>(8, (int) (LDS / blk) * w);
-  };
-  const int wmax = (variant == MTP_VARIANT_SMALL || (variant == MTP_VARIANT_AUTO && inum < num_cus * 16))
-      ? 2 : MTP_MAX_WPB;
-  int best_nt = 0, best_w = 0, best = 0;
-  for (int nt : {32})
+  const int nt = 32;
+  for (int g = 0; g < 2; g++) {
+    LaunchPlan &L = lp[g];
+    L.tab_rows = 2 * p.slot_count + 3 * P + (g ? P + p.radial_basis_size : 0);
+    L.g_doubles = g ? p.radial_func_count * nt + p.species_count * p.radial_func_count * p.radial_basis_size : 0;
+    L.m_doubles = std::max(std::max(A, 4 * KL * KB), 144);
+    const size_t dbl = (size_t) A + L.m_doubles + (size_t) L.tab_rows * (nt + 2) + 5 * (size_t) nt + 64 + L.g_doubles;
+    const size_t ints = (size_t) 2 * nt + cap;
+    const size_t wb = (dbl * 8 + ints * 4 + 15) / 16 * 16;
+    // waves per CU for w waves per workgroup; registers allow 8 (2 per SIMD)
+    auto waves_per_cu = [&](int w) {
+      size_t blk = blob + w * wb;
+      if (blk > LDS) return 0;
+      return std::min<int>(8, (int) (LDS / blk) * w);
+    };
+    const int wmax = (variant == MTP_VARIANT_SMALL || (variant == MTP_VARIANT_AUTO && inum < num_cus * 16))
+        ? 2 : MTP_MAX_WPB;
+    int best_w = 0, best = 0;
     for (int w = 1; w <= wmax; w++) {
-      int v = waves_per_cu(nt, w);
-      // prefer occupancy; at equal occupancy the larger tile, then fewer waves per workgroup
-      // when the shared blob is small (finer-grained scheduling), more when it is big
-      if (v > best || (v == best && v > 0 && nt == best_nt && blob > 16384 && w > best_w)) {
+      int v = waves_per_cu(w);
+      // prefer occupancy; at equal occupancy more waves per workgroup when the shared blob is big
+      if (v > best || (v == best && v > 0 && blob > 16384 && w > best_w)) {
         best = v;
-        best_nt = nt;
         best_w = w;
       }
     }
-  if (best == 0) throw HipFail{hipErrorInvalidValue, "potential + neighbour list exceed one CU's LDS"};
-  if (variant == MTP_VARIANT_SMALL) {   // one wavefront per workgroup: finest spread of few atoms
-    best_w = 1;
-    best = waves_per_cu(best_nt, 1);
+    if (best == 0) throw HipFail{hipErrorInvalidValue, "potential + neighbour list exceed one CU's LDS"};
+    if (variant == MTP_VARIANT_SMALL) best_w = 1;   // finest spread of few atoms
+    if (const char *e = std::getenv("MTP_WPB")) {   // tuning override (benchmarks only)
+      int v = std::atoi(e);
+      if (v >= 1 && v <= MTP_MAX_WPB && waves_per_cu(v) > 0) best_w = v;
+    }
+    best = std::max(1, waves_per_cu(best_w));
+    L.wpb = best_w;
+    L.wave_doubles = (int) (wb / 8);
+    L.lds_bytes = blob + wb * best_w;
+    const int blocks_per_cu = std::max(1, best / best_w);
+    const int need = (inum + best_w - 1) / best_w;
+    L.grid = std::max(1, std::min(need, num_cus * blocks_per_cu));
   }
-  // tuning overrides (benchmarks only)
-  if (const char *e = std::getenv("MTP_NT")) {
-    int v = std::atoi(e);
-    if (v == 32 && waves_per_cu(v, best_w) > 0) best_nt = v;
-  }
-  if (const char *e = std::getenv("MTP_WPB")) {
-    int v = std::atoi(e);
-    if (v >= 1 && v <= MTP_MAX_WPB && waves_per_cu(best_nt, v) > 0) best_w = v;
-  }
-  best = std::max(1, waves_per_cu(best_nt, best_w));
-  NT = best_nt;
-  wpb = best_w;
-  size_t wb = wave_bytes(NT);
-  wave_doubles = (int) (wb / 8);
-  lds_bytes = blob + wb * wpb;
-  const int blocks_per_cu = std::max(1, best / wpb);
-  const int need = (inum + wpb - 1) / wpb;
-  grid = std::max(1, std::min(need, num_cus * blocks_per_cu));
-  base.NT = NT;
-  base.tab_rows = tab_rows;
-  base.m_doubles = m_doubles;
+  base.NT = nt;
   base.cj_cap = cap;
-  base.wave_doubles = wave_doubles;
 }
 
 extern "C" {
@@ -309,7 +301,15 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     blob.resize((blob.size() + 15) / 16 * 16, 0);
     bb.blob_bytes = (int) blob.size();
     c->d_blob.upload(blob.data(), blob.size(), st);
-    if (pot->has_selection) c->d_inv_active.upload(pot->inverse_active_set, st);
+    if (pot->has_selection) {   // inverse active set zero padded to a multiple of 16 for the MFMA grade kernel
+      const int C = pot->coeff_count;
+      c->cpad = (C + 15) / 16 * 16;
+      std::vector<double> pad((size_t) c->cpad * c->cpad, 0.0);
+      for (int r = 0; r < C; r++)
+        std::memcpy(&pad[(size_t) r * c->cpad], &pot->inverse_active_set[(size_t) r * C], (size_t) C * sizeof(double));
+      c->d_ainv_pad.upload(pad, st);
+      HIP_CHECK(hipStreamSynchronize(st));
+    }
     c->d_ev_slots.reserve((size_t) MTP_EV_SLOTS * 8);
     HIP_CHECK(hipMemsetAsync(c->d_ev_slots.ptr, 0, (size_t) MTP_EV_SLOTS * 8 * sizeof(double), st));
     c->d_ev.reserve(8);
@@ -341,7 +341,6 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     b.rows = c->d_rows.ptr;
     b.species_coeffs = c->d_species.ptr;
     b.inv_mu = 1.0f / (float) pot->radial_func_count;
-    b.inv_active = pot->has_selection ? c->d_inv_active.ptr : nullptr;
     b.ev_slots = c->d_ev_slots.ptr;
     b.err_flag = c->d_err.ptr;
     b.stamps = c->d_stamps.ptr;
@@ -398,10 +397,17 @@ static int finish_list(mtp_context *c, int inum, int nall, int max_numneigh)
   c->have_list = true;
   try {
     c->plan();
+    if (c->pot->has_selection && inum > 0) {   // candidate vectors, zero padded rows of cpad doubles
+      const size_t n = (size_t) inum * c->cpad;
+      if (n > c->d_cvec.cap) {
+        c->d_cvec.reserve(n);
+        HIP_CHECK(hipMemset(c->d_cvec.ptr, 0, n * sizeof(double)));
+      }
+    }
   } catch (const HipFail &f) {
     c->last_error = f.what;
     c->have_list = false;
-    return MTP_ERR_LIMIT;
+    return f.e == hipErrorInvalidValue ? MTP_ERR_LIMIT : MTP_ERR_DEVICE;
   }
   return MTP_OK;
 }
@@ -469,9 +475,20 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
     c->last_error = "extrapolation grades requested but the potential has no #MVS_v1.1 selection state";
     return MTP_ERR_STATE;
   }
+  const bool cfg = c->pot->configuration_mode;
   if (grade_flag) {
-    c->last_error = "extrapolation grades are not implemented in this build";
-    return MTP_ERR_STATE;
+    if (!cfg && !d_grades) {
+      c->last_error = "neighbourhood-mode grades need a grades array";
+      return MTP_ERR_ARG;
+    }
+    if (cfg && !d_coeff_ders) {
+      c->last_error = "configuration-mode grades need a coeff_ders array";
+      return MTP_ERR_ARG;
+    }
+    if (c->pot->species_count * c->pot->radial_func_count * c->pot->radial_basis_size > 256) {
+      c->last_error = "Sp*Mu*R above 256 is not supported by the grade kernels of this build";
+      return MTP_ERR_LIMIT;
+    }
   }
   if (((eflag & MTP_ENERGY_GLOBAL) || vflag) && !d_ev) return MTP_ERR_ARG;
   if (c->inum == 0) return MTP_OK;
@@ -487,12 +504,16 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
   p.f = d_f;
   p.eatom = d_eatom;
   p.vatom = d_vatom;
-  p.grades = d_grades;
-  p.max_grade = d_max_grade;
-  p.coeff_ders = d_coeff_ders;
   p.eflag = eflag;
   p.vflag = vflag;
-  p.grade_flag = grade_flag;
+  p.grade_flag = grade_flag ? 1 : 0;
+  const mtp_context::LaunchPlan &L = c->lp[grade_flag ? 1 : 0];
+  p.tab_rows = L.tab_rows;
+  p.g_doubles = L.g_doubles;
+  p.m_doubles = L.m_doubles;
+  p.wave_doubles = L.wave_doubles;
+  p.cvec = grade_flag ? c->d_cvec.ptr : nullptr;
+  p.cpad = c->cpad;
   try {
     if (c->timing) {
       if (!c->ev0) {
@@ -501,12 +522,19 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
       }
       HIP_CHECK(hipEventRecord(c->ev0, st));
     }
-    HIP_CHECK(mtp_launch_wave_kernel(p, c->grid, c->wpb, c->lds_bytes, st));
+    HIP_CHECK(mtp_launch_wave_kernel(p, L.grid, L.wpb, L.lds_bytes, st));
     if (c->timing) {
       HIP_CHECK(hipEventRecord(c->ev1, st));
       c->timed = true;
     }
     if ((eflag & MTP_ENERGY_GLOBAL) || vflag) HIP_CHECK(mtp_launch_ev_finish(c->d_ev_slots.ptr, d_ev, st));
+    if (grade_flag) {
+      if (cfg)
+        HIP_CHECK(mtp_launch_colsum_kernel(c->d_cvec.ptr, c->cpad, c->pot->coeff_count, c->inum, d_coeff_ders, st));
+      else
+        HIP_CHECK(mtp_launch_grade_kernel(c->d_cvec.ptr, c->d_ainv_pad.ptr, c->cpad, c->pot->coeff_count, c->inum,
+                                          c->ilist, d_grades, d_max_grade, st));
+    }
   } catch (const HipFail &f) {
     c->last_error = std::string(f.what) + ": " + hipGetErrorString(f.e);
     return MTP_ERR_DEVICE;
@@ -604,10 +632,10 @@ int mtp_context_launch_info(const mtp_context *c, int32_t *lds_bytes_per_wave, i
                             int32_t *grid_blocks, int32_t *neighbor_tile)
 {
   if (!c || !c->have_list) return MTP_ERR_STATE;
-  if (lds_bytes_per_wave) *lds_bytes_per_wave = c->wave_doubles * 8;
-  if (waves_per_block) *waves_per_block = c->wpb;
-  if (grid_blocks) *grid_blocks = c->grid;
-  if (neighbor_tile) *neighbor_tile = c->NT;
+  if (lds_bytes_per_wave) *lds_bytes_per_wave = c->lp[0].wave_doubles * 8;
+  if (waves_per_block) *waves_per_block = c->lp[0].wpb;
+  if (grid_blocks) *grid_blocks = c->lp[0].grid;
+  if (neighbor_tile) *neighbor_tile = c->base.NT;
   return MTP_OK;
 }
 

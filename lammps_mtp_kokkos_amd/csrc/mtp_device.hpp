@@ -31,11 +31,10 @@ struct MtpDevParams {
   int off_seed_val;        // double[nseed]
   int off_map;             // int[S]
   int off_lin;             // double[S]
-  int off_pack;            // int[B] slot | a<<8 | b<<12 | c<<16
+  int off_pack;            // int[B] slot | a<<8 | b<<12 | c<<16 | mu<<20
   int rows_in_lds;
   const MtpRow8 *rows;     // [T] by level, in HBM (always valid)
   const double *species_coeffs;
-  const double *inv_active;   // [C][C] or null
   // system
   int inum, nall;
   const int *ilist, *first, *neigh;
@@ -46,18 +45,18 @@ struct MtpDevParams {
   double *eatom;           // [nall] or null
   double *vatom;           // [nall][6] or null
   double *ev_slots;        // [MTP_EV_SLOTS][8]
-  double *grades;          // [nall] or null
-  double *max_grade;       // [1] or null
-  double *coeff_ders;      // [C] or null
+  double *cvec;            // [inum][cpad] candidate vectors dE_i/dtheta (grade calls only)
+  int cpad;                // row stride of cvec and of the padded inverse active set (multiple of 16)
   int *err_flag;
   unsigned long long *stamps;   // [16] diagnostic build only (MTP_STAMPS), else unused
   int eflag, vflag, grade_flag;
   // launch geometry
   int NT;                  // neighbours per LDS tile: 32 or 16 (table row pitch = NT + 2 doubles)
-  int tab_rows;            // table rows = 2*nslot + 3*P
+  int tab_rows;            // table rows = 2*nslot + 3*P (+ P + R in grade calls: r^-nu and Q_ri rows)
   int cj_cap;              // capacity of the compacted id list
   int wave_doubles;        // LDS doubles per wavefront
   int m_doubles;           // doubles of the moment region = max(A, 4*KL*KB)
+  int g_doubles;           // grade calls: Mu*NT + Sp*Mu*R scratch doubles, else 0
   float inv_mu;            // 1 / Mu
 };
 
@@ -65,3 +64,8 @@ struct MtpDevParams {
 int mtp_pick_shape(int B, int *KL, int *KB);
 hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);
 hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st);
+// grades[ilist[ii]] = max_r |sum_c cvec[ii][c] Ainv[r][c]| (f64 MFMA), running maximum into max_grade
+hipError_t mtp_launch_grade_kernel(const double *cvec, const double *ainv_pad, int cpad, int C, int inum,
+                                   const int *ilist, double *grades, double *max_grade, hipStream_t st);
+// coeff_ders[c] += sum_ii cvec[ii][c]
+hipError_t mtp_launch_colsum_kernel(const double *cvec, int cpad, int C, int inum, double *coeff_ders, hipStream_t st);

@@ -118,7 +118,7 @@ struct BlockTables {   // views into the workgroup-shared head of LDS
 
 template <int PITCH> struct WaveLds {
   static constexpr int NT = PITCH - 2;
-  double *M, *D, *tab, *nbx, *nby, *nbz, *nbr, *nbi, *red;
+  double *M, *D, *tab, *nbx, *nby, *nbz, *nbr, *nbi, *red, *gw;
   int *nbj, *nbjt, *cj;
   unsigned m_addr;   // LDS byte address of M
   __device__ __forceinline__ unsigned addr(const double *ptr) const { return m_addr + 8u * (unsigned) (ptr - M); }
@@ -134,7 +134,8 @@ template <int PITCH> struct WaveLds {
     nbr = nbz + NT;
     nbi = nbr + NT;
     red = nbi + NT;   // 64 doubles
-    nbj = reinterpret_cast<int *>(red + 64);
+    gw = red + 64;    // grade calls only: W[mu][n] (Mu*NT) + staged radial block (Sp*Mu*R)
+    nbj = reinterpret_cast<int *>(gw + p.g_doubles);
     nbjt = nbj + NT;
     cj = nbjt + NT;
   }
@@ -142,7 +143,7 @@ template <int PITCH> struct WaveLds {
 
 // Phase 2: tables of one tile; columns [0, ntp) are written, ntp = nt rounded up to the
 // neighbour-group count with dummy neighbours sitting exactly on the cutoff (g = dg = 0).
-template <int PITCH>
+template <int PITCH, bool GRADE>
 __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTables &bt, const WaveLds<PITCH> &w,
                                            int t0, int cnt, int ntp, bool gather, double xi0, double xi1,
                                            double xi2, int i, int itype, int lane)
@@ -181,13 +182,19 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
     double q0 = p.scaling * (d * d), q1 = p.scaling * (ksi * d * d);
     double e0 = p.scaling * 2.0 * d, e1 = p.scaling * (mult * d * d + 2.0 * ksi * d);
     double val = c[0] * q0, der = c[0] * e0;
+    // grade calls keep Q_ri(r_n) and r_n^-nu as extra rows (pair_mtp_extrapolation.cpp:193-198)
+    const bool extra = GRADE && mu == 0;
+    double *colq = w.tab + (size_t) (2 * p.nslot + 4 * P) * PITCH + n;
+    if (extra) colq[0] = q0;
     if (R > 1) {
       val += c[1] * q1;
       der += c[1] * e1;
+      if (extra) colq[PITCH] = q1;
     }
     for (int ri = 2; ri < R; ri++) {
       const double q2 = 2.0 * ksi * q1 - q0;
       const double e2 = 2.0 * (mult * q1 + ksi * e1) - e0;
+      if (extra) colq[ri * PITCH] = q2;
       val += c[ri] * q2;
       der += c[ri] * e2;
       q0 = q1;
@@ -205,6 +212,7 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
         col[s * PITCH] = g;                                       // f_mu / r^nu
         col[(p.nslot + s) * PITCH] = der * rp - nu * g * inv;     // d/dr (f_mu / r^nu)
       }
+      if (extra) col[(2 * p.nslot + 3 * P + nu) * PITCH] = rp;    // r^-nu
       rp *= inv;
     }
   }
@@ -275,7 +283,7 @@ __device__ __forceinline__ void products_backward(const MtpRow8 *rows, const int
   }
 }
 
-template <int KL, int KB, int PITCH>
+template <int KL, int KB, int PITCH, bool GRADE>
 __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
 {
   constexpr int NT = PITCH - 2;          // neighbours per tile (32 or 16)
@@ -412,7 +420,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     const int ntiles = (cnt + NT - 1) / NT;
     for (int tile = 0; tile < ntiles; tile++) {
       const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-      build_tile<PITCH>(p, bt, w, t0, cnt, ntp, tile > 0, xi0, xi1, xi2, i, itype, lane);
+      build_tile<PITCH, GRADE>(p, bt, w, t0, cnt, ntp, tile > 0, xi0, xi1, xi2, i, itype, lane);
       STAMP(2);   // tile tables
 #pragma unroll
       for (int m = 0; m < NPG; m++) {
@@ -447,6 +455,12 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     if (rows_lds) products_forward(bt.rows, bt.level, p.nlevels, w.M, lane);
     else products_forward(p.rows, bt.level, p.nlevels, w.M, lane);
     STAMP(4);   // products forward
+    // ---- candidate vector, species and linear blocks (pair_mtp_extrapolation.cpp:235-252) ----
+    if (GRADE) {
+      double *crow = p.cvec + (size_t) ii * p.cpad + p.Sp * p.Sp * p.Mu * p.R;
+      for (int k = lane; k < p.Sp; k += 64) crow[k] = k == itype ? 1.0 : 0.0;
+      for (int k = lane; k < p.S; k += 64) crow[p.Sp + k] = w.M[bt.map[k]];
+    }
     // ---- site energy (pair_mtp.cpp:204-212) ----------------------------------------------
     double e = 0.0;
     for (int k = lane; k < p.S; k += 64) e += bt.lin[k] * w.M[bt.map[k]];
@@ -477,9 +491,10 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     wave_fence();
     // the 16 lanes with kl < BATCH collect: force on i (3), virial (6)
     double fi0 = 0, fi1 = 0, fi2 = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+    double crad[4] = {0.0, 0.0, 0.0, 0.0};   // grade calls: this lane's entries of the radial block
     for (int tile = 0; tile < ntiles; tile++) {
       const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-      if (ntiles > 1) build_tile<PITCH>(p, bt, w, t0, cnt, ntp, true, xi0, xi1, xi2, i, itype, lane);
+      if (ntiles > 1) build_tile<PITCH, GRADE>(p, bt, w, t0, cnt, ntp, true, xi0, xi1, xi2, i, itype, lane);
 #pragma unroll
       for (int b = 0; b < NBATCH; b++) {
         if (b * BATCH * NG < ntp) {
@@ -535,6 +550,72 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
           }
           wave_fence();
         }
+      }
+      // ---- radial block of the candidate vector (pair_mtp_extrapolation.cpp:193-198, 323-329):
+      // c[jt][mu][ri] = sum_n [type_n = jt] Q_ri(r_n) W_mu(n),  W_mu(n) = sum_{k in mu} D_k mono_k(n) / r_n^nu_k
+      if (GRADE) {
+        const int row_r0 = 2 * ns + 3 * P, row_q0 = 2 * ns + 4 * P;
+        for (int mu0 = 0; mu0 < p.Mu; mu0 += 4) {
+#pragma unroll
+          for (int b = 0; b < NBATCH; b++) {
+            if (b * BATCH * NG < ntp) {
+              double wp[KL];
+#pragma unroll
+              for (int u = 0; u < KL; u++) wp[u] = 0.0;
+#pragma unroll
+              for (int t = 0; t < KB; t++) {
+                const int k = kl + KL * t;
+                const int pk = k < p.B ? bt.pack[k] : 0;
+                const int ml = ((pk >> 20) & 15) - mu0;
+                const int nu = ((pk >> 8) & 15) + ((pk >> 12) & 15) + ((pk >> 16) & 15);
+                const double Dk = lds_ld(pda, KL * t);
+                unsigned pr = w.addr(w.tab + (size_t) (row_r0 + nu) * PITCH + q);
+                asm volatile("" : "+v"(pr));
+#pragma unroll
+                for (int mm = 0; mm < BATCH; mm++) {
+                  const int o = (b * BATCH + mm) * NG;
+                  const double val = (Dk * lds_ld(pr, o)) *
+                      (lds_ld(px[t], PITCH + o) * (lds_ld(py[t], PITCH + o) * lds_ld(pz[t], PITCH + o)));
+#pragma unroll
+                  for (int u = 0; u < 4; u++) wp[4 * mm + u] += ml == u ? val : 0.0;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              Butterfly<KL>::run(wp, lane);
+              const int mm = kl >> 2, mu = mu0 + (kl & 3);
+              const int n = q + NG * (b * BATCH + mm);
+              if (n < nt && mu < p.Mu) w.gw[mu * NT + n] = wp[0];
+            }
+          }
+        }
+        wave_fence();
+        const int MuR = p.Mu * p.R;
+#pragma unroll
+        for (int ce = 0; ce < 4; ce++) {
+          const int e = lane + 64 * ce;
+          if (e < p.Sp * MuR) {
+            const int jt = e / MuR, m = e - jt * MuR, mu = m / p.R, ri = m - mu * p.R;
+            const double *qrow = w.tab + (size_t) (row_q0 + ri) * PITCH;
+            double sum = 0.0;
+            for (int n = 0; n < nt; n++)
+              if (w.nbjt[n] == jt) sum += qrow[n] * w.gw[mu * NT + n];
+            crad[ce] += sum;
+          }
+        }
+        wave_fence();
+      }
+    }
+    if (GRADE) {   // stage the radial block, then write the whole radial part of the row
+      const int SMR = p.Sp * p.Mu * p.R;
+      double *stage = w.gw + p.Mu * NT;
+#pragma unroll
+      for (int ce = 0; ce < 4; ce++)
+        if (lane + 64 * ce < SMR) stage[lane + 64 * ce] = crad[ce];
+      wave_fence();
+      double *crow = p.cvec + (size_t) ii * p.cpad;
+      for (int e = lane; e < p.Sp * SMR; e += 64) {
+        const int blk = e / SMR;
+        crow[e] = blk == itype ? stage[e - blk * SMR] : 0.0;   // offset (itype*Sp + jt)*MuR + m
       }
     }
     STAMP(7);   // forces
@@ -595,17 +676,96 @@ __global__ void mtp_ev_finish(double *ev_slots, double *ev)
   if (threadIdx.x == 0) ev[q] += s;
 }
 
-template <int KL, int KB, int PITCH>
+
+// ---- MaxVol grade: grades[i] = max_r | sum_c cvec[i][c] Ainv[r][c] |  (pair_mtp_extrapolation.cpp:347-358)
+// One inverse active set for every atom: a dense [atoms x C] x [C x C] fp64 contraction, done on
+// the matrix cores with v_mfma_f64_16x16x4_f64.  One wavefront owns 16 atoms; M = atoms, N = rows of
+// Ainv, K = coefficients.  Operand lane maps (cdna_hip_programming.md section 3): A[i = l&15][k = l>>4],
+// B[k = l>>4][j = l&15], D: col = l&15, row = (l>>4) + 4*reg.  Both arrays are zero padded to cpad
+// (multiple of 16), so no bounds checks on c or r.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+template <int KS_REG>   // > 0: the 16 x cpad block of cvec lives in registers (cpad <= 4*KS_REG)
+__global__ void __launch_bounds__(256) mtp_grade_kernel(const double *__restrict__ cvec,
+                                                       const double *__restrict__ ainv, int cpad, int inum,
+                                                       const int *__restrict__ ilist, double *grades,
+                                                       double *max_grade)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int atom0 = (blockIdx.x * 4 + wave) * 16;
+  if (atom0 >= inum) return;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ksteps = cpad >> 2;
+  const int arow = min(atom0 + li, inum - 1);   // clamped: rows past the end are computed and dropped
+  const double *ap = cvec + (size_t) arow * cpad + lk;
+  double areg[KS_REG > 0 ? KS_REG : 1];
+  if (KS_REG > 0) {
+#pragma unroll
+    for (int ks = 0; ks < KS_REG; ks++) areg[ks] = ks < ksteps ? ap[4 * ks] : 0.0;
+  }
+  double gmax[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int n0 = 0; n0 < cpad; n0 += 16) {
+    const double *bp = ainv + (size_t) (n0 + li) * cpad + lk;   // B[k][j] = Ainv[n0 + j][k]
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    if (KS_REG > 0) {
+#pragma unroll
+      for (int ks = 0; ks < KS_REG; ks++)
+        if (ks < ksteps) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[ks], bp[4 * ks], acc, 0, 0, 0);
+    } else {
+      for (int ks = 0; ks < ksteps; ks++)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * ks], bp[4 * ks], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) gmax[r] = fmax(gmax[r], fabs(acc[r]));
+  }
+  // max over the 16 lanes (Ainv rows) that share l>>4
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+#pragma unroll
+    for (int sft = 1; sft < 16; sft <<= 1) gmax[r] = fmax(gmax[r], shfl_xor_f64(gmax[r], sft));
+  }
+  double wmax = 0.0;
+  if (li == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int a = atom0 + lk + 4 * r;   // D row = (l>>4) + 4*reg
+      if (a < inum) {
+        grades[ilist[a]] = gmax[r];   // pair_mtp_extrapolation.cpp:335
+        wmax = fmax(wmax, gmax[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int sft = 16; sft < 64; sft <<= 1) wmax = fmax(wmax, shfl_xor_f64(wmax, sft));
+  // grades are >= 0, so their IEEE bit patterns order like unsigned integers
+  if (lane == 0 && max_grade)
+    atomicMax(reinterpret_cast<unsigned long long *>(max_grade), (unsigned long long) __double_as_longlong(wmax));
+}
+
+// configuration mode: coeff_ders[c] += sum_i cvec[i][c]  (pair_mtp_extrapolation.cpp:97-98, 240-252, 327)
+__global__ void __launch_bounds__(256) mtp_colsum_kernel(const double *__restrict__ cvec, int cpad, int C, int inum,
+                                                        double *coeff_ders)
+{
+  const int rows_per_block = 256;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(inum, r0 + rows_per_block);
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = r0; r < r1; r++) s += cvec[(size_t) r * cpad + c];
+  unsafeAtomicAdd(&coeff_ders[c], s);
+}
+
+template <int KL, int KB, int PITCH, bool GRADE>
 hipError_t launch_one(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
 {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mtp_wave_kernel<KL, KB, PITCH>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mtp_wave_kernel<KL, KB, PITCH, GRADE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((mtp_wave_kernel<KL, KB, PITCH>), dim3(grid), dim3(64 * wpb), lds, st, p);
+  hipLaunchKernelGGL((mtp_wave_kernel<KL, KB, PITCH, GRADE>), dim3(grid), dim3(64 * wpb), lds, st, p);
   return hipGetLastError();
 }
 
@@ -613,7 +773,9 @@ template <int KL, int KB> hipError_t launch_pitch(const MtpDevParams &p, int gri
 {
   // only the 32-neighbour tile (pitch 34) is instantiated: hipcc 7.2 rejects the pitch-18 and
   // KB = 1 shapes with a machine-verifier error ("Operand has incorrect register class")
-  return launch_one<KL, KB, 34>(p, grid, wpb, lds, st);
+  // the grade variant is its own instantiation so the force-only kernel keeps its register budget
+  return p.grade_flag ? launch_one<KL, KB, 34, true>(p, grid, wpb, lds, st)
+                      : launch_one<KL, KB, 34, false>(p, grid, wpb, lds, st);
 }
 
 }   // namespace
@@ -660,6 +822,27 @@ hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size
   MTP_CASE(64, 10)
 #undef MTP_CASE
   return hipErrorInvalidValue;
+}
+
+hipError_t mtp_launch_grade_kernel(const double *cvec, const double *ainv_pad, int cpad, int C, int inum,
+                                   const int *ilist, double *grades, double *max_grade, hipStream_t st)
+{
+  (void) C;
+  const int blocks = (inum + 63) / 64;
+  if (cpad <= 160)
+    hipLaunchKernelGGL(mtp_grade_kernel<40>, dim3(blocks), dim3(256), 0, st, cvec, ainv_pad, cpad, inum, ilist, grades,
+                       max_grade);
+  else
+    hipLaunchKernelGGL(mtp_grade_kernel<0>, dim3(blocks), dim3(256), 0, st, cvec, ainv_pad, cpad, inum, ilist, grades,
+                       max_grade);
+  return hipGetLastError();
+}
+
+hipError_t mtp_launch_colsum_kernel(const double *cvec, int cpad, int C, int inum, double *coeff_ders, hipStream_t st)
+{
+  hipLaunchKernelGGL(mtp_colsum_kernel, dim3((C + 255) / 256, (inum + 255) / 256), dim3(256), 0, st, cvec, cpad, C, inum,
+                     coeff_ders);
+  return hipGetLastError();
 }
 
 hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st)

@@ -400,7 +400,11 @@ int mtp_potential::finalize(std::string &err)
       err = "more than 256 distinct (mu, nu) radial slots";
       return MTP_ERR_LIMIT;
     }
-    basic_pack[i] = s | (q[1] << 8) | (q[2] << 12) | (q[3] << 16);
+    if (q[0] > 15) {
+      err = "radial function index above 15 is not supported";
+      return MTP_ERR_LIMIT;
+    }
+    basic_pack[i] = s | (q[1] << 8) | (q[2] << 12) | (q[3] << 16) | (q[0] << 20);
   }
   return MTP_OK;
 }

@@ -36,7 +36,7 @@ struct mtp_potential {
   // distinct (mu, nu) pairs used by the basics -> slot; slot_of[mu*P+nu] or -1
   std::vector<int32_t> slot_of;
   int slot_count = 0;
-  // per basic: slot | a<<8 | b<<12 | c<<16 (what a lane needs per k)
+  // per basic: slot | a<<8 | b<<12 | c<<16 | mu<<20 (what a lane needs per k)
   std::vector<int32_t> basic_pack;
   // adjoint seeds: D[idx] = val (last mapping entry wins, pair_mtp.cpp:217-218)
   std::vector<int32_t> seed_idx;

@@ -271,3 +271,75 @@ def test_config2_size_properties_64k_atoms():
     # translation of the whole crystal changes nothing
     r2 = ctx.compute(s.x + np.array([0.37, -1.1, 2.2]), s.types)
     _close(r2["f"], r["f"], "translated forces", atol=1e-8)
+
+
+# ---- MaxVol extrapolation grades (pair_style mtp/extrapolation) -------------------------------------
+
+
+def _grade_compare(path, s, natoms=None):
+    pot = capi.Potential(path, selection=True)
+    ctx = capi.Context(pot, 0)
+    ctx.set_neighbors(s.ilist, s.first, s.neigh, s.nall)
+    got = ctx.compute(s.x, s.types, grade=True)
+    want = _oracle(path, selection=True).compute(s.x, s.types, s.ilist, s.first, s.neigh, extrapolation=True,
+                                                 natoms=natoms or s.nlocal)
+    _close(got["f"], want["f"], "forces (grade call)")
+    _close(got["eatom"], want["eatom"], "eatom (grade call)", atol=1e-10)
+    return pot, got, want
+
+
+def test_neighbourhood_grades_level16():
+    s = _system((4, 4, 4))
+    pot, got, want = _grade_compare(os.path.join(POT, "W_L16_nbh.almtp"), s)
+    assert not pot.info.configuration_mode
+    _close(got["grades"][s.ilist], want["grades"][s.ilist], "grades", atol=1e-9, rtol=1e-9)
+    assert abs(got["max_grade"] - want["max_grade"]) <= 1e-9 * max(1.0, want["max_grade"])
+    assert not got["grades"][s.nlocal:].any()          # ghosts untouched
+
+
+def test_neighbourhood_grades_two_species_multi_tile(tmp_path):
+    tab = mtpgen.build_table(10)
+    p = mtpgen.random_potential(tab, 2, 77)
+    mtpgen.add_selection_state(p, "nbh", seed=5)
+    path = str(tmp_path / "nbh2.almtp")
+    mtpgen.write_mtp(p, path)
+    s = _system((4, 4, 4), species=2, a=2.6, list_cutoff=6.0)      # > 32 in-cutoff neighbours
+    pot, got, want = _grade_compare(path, s)
+    _close(got["grades"][s.ilist], want["grades"][s.ilist], "grades", atol=1e-9, rtol=1e-9)
+    assert abs(got["max_grade"] - want["max_grade"]) <= 1e-9 * max(1.0, want["max_grade"])
+
+
+def test_configuration_mode_candidate_vector():
+    s = _system((3, 3, 3), species=2)
+    path = os.path.join(POT, "WRe_L10_cfg.almtp")
+    pot, got, want = _grade_compare(path, s)
+    assert pot.info.configuration_mode
+    _close(got["coeff_ders"], want["coeff_ders"], "sum_i dE_i/dtheta", atol=1e-9, rtol=1e-10)
+    g = pot.cfg_grade(got["coeff_ders"]) / s.nlocal                 # compile_grades, :369-376
+    assert abs(g - want["max_grade"]) <= 1e-9 * max(1.0, want["max_grade"])
+
+
+def test_grades_without_selection_state_is_an_error():
+    s = _system((2, 2, 2))
+    pot = capi.Potential(os.path.join(POT, "W_L8.mtp"))
+    ctx = capi.Context(pot, 0)
+    ctx.set_neighbors(s.ilist, s.first, s.neigh, s.nall)
+    with pytest.raises(capi.MtpError) as ei:
+        ctx.compute(s.x, s.types, grade=True)
+    assert ei.value.code == -23
+
+
+def test_golden_grades():
+    gdir = os.path.join(ROOT, "tests", "golden")
+    for n in ("W_L16_nbh_16.npz", "WRe_L10_cfg_16.npz"):
+        g = np.load(os.path.join(gdir, n))
+        pot = capi.Potential(os.path.join(POT, str(g["potential"])), selection=True)
+        ctx = capi.Context(pot, 0)
+        ctx.set_neighbors(g["ilist"], g["first"], g["neigh"], len(g["x"]))
+        r = ctx.compute(g["x"], g["types"], grade=True)
+        _close(r["f"], g["f"], n + " forces")
+        if pot.info.configuration_mode:
+            _close(r["coeff_ders"], g["coeff_ders"], n + " coeff_ders", rtol=1e-10)
+        else:
+            _close(r["grades"], g["grades"], n + " grades", rtol=1e-9)
+            assert abs(r["max_grade"] - float(g["max_grade"])) <= 1e-9 * max(1.0, float(g["max_grade"]))
