@@ -61,6 +61,14 @@ __device__ __forceinline__ void wave_fence()
 
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
 
+__device__ __forceinline__ double uniform_f64(double v)   // v is wave-uniform: move it to SGPRs
+{
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) b);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned) (b >> 32));
+  return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -351,14 +359,17 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
 #endif
 
   for (int ii = blockIdx.x * wpb + wave; ii < p.inum; ii += gridDim.x * wpb) {
-    const int i = p.ilist[ii];
-    const int itype = p.type[i] - 1;
+    // ii is wave-uniform, so is everything loaded through it: keep it in SGPRs
+    const int i = __builtin_amdgcn_readfirstlane(p.ilist[ii]);
+    const int itype = __builtin_amdgcn_readfirstlane(p.type[i] - 1);
     if (itype < 0 || itype >= p.Sp) {   // pair_mtp.cpp:91-93
       if (lane == 0) atomicExch(p.err_flag, 1);
       continue;
     }
-    const double xi0 = p.x[3 * (size_t) i], xi1 = p.x[3 * (size_t) i + 1], xi2 = p.x[3 * (size_t) i + 2];
-    const int jbeg = p.first[ii], jnum = p.first[ii + 1] - jbeg;
+    const double xi0 = uniform_f64(p.x[3 * (size_t) i]), xi1 = uniform_f64(p.x[3 * (size_t) i + 1]),
+                 xi2 = uniform_f64(p.x[3 * (size_t) i + 2]);
+    const int jbeg = __builtin_amdgcn_readfirstlane(p.first[ii]);
+    const int jnum = __builtin_amdgcn_readfirstlane(p.first[ii + 1]) - jbeg;
 
     STAMP(0);   // loop head: ilist/type/x/first loads issue
     // ---- 1. compaction (the first NT survivors go straight into the tile arrays) --------
@@ -425,11 +436,20 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
 #pragma unroll
       for (int m = 0; m < NPG; m++) {
         if (m * NG < ntp) {
+          // all 4*KB reads of this column issue back to back (one LDS latency), then the FMAs;
+          // the barriers keep the scheduler from either splitting the burst or hoisting every
+          // column's reads (register blow-up)
+          double G[KB], X[KB], Y[KB], Z[KB];
 #pragma unroll
-          for (int t = 0; t < KB; t++)
-            acc[t] += lds_ld(pg[t], m * NG) *
-                (lds_ld(px[t], PITCH + m * NG) * (lds_ld(py[t], PITCH + m * NG) * lds_ld(pz[t], PITCH + m * NG)));
-          // without this the scheduler hoists every tile read above the first FMA and spills
+          for (int t = 0; t < KB; t++) {
+            G[t] = lds_ld(pg[t], m * NG);
+            X[t] = lds_ld(px[t], PITCH + m * NG);
+            Y[t] = lds_ld(py[t], PITCH + m * NG);
+            Z[t] = lds_ld(pz[t], PITCH + m * NG);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < KB; t++) acc[t] += G[t] * (X[t] * (Y[t] * Z[t]));
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -506,18 +526,33 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
           for (int t = 0; t < KB; t++) {
             const double Dk = lds_ld(pda, KL * t), Da = lds_ld(pda, KP + KL * t);
             const double Db = lds_ld(pda, 2 * KP + KL * t), Dc = lds_ld(pda, 3 * KP + KL * t);
+            constexpr int MC = BATCH < 4 ? BATCH : 4;   // columns per burst (8 reads each)
 #pragma unroll
-            for (int mm = 0; mm < BATCH; mm++) {
-              const int o = (b * BATCH + mm) * NG;   // column offset of this lane's neighbour
-              const double g = lds_ld(pg[t], o), gd = lds_ld(pd[t], o);
-              const double xm = lds_ld(px[t], o), xa = lds_ld(px[t], PITCH + o);
-              const double ym = lds_ld(py[t], o), yb = lds_ld(py[t], PITCH + o);
-              const double zm = lds_ld(pz[t], o), zc = lds_ld(pz[t], PITCH + o);
-              const double yz = yb * zc, xz = xa * zc, xy = xa * yb;
-              part[4 * mm + 0] += (Dk * gd) * (xa * yz);
-              part[4 * mm + 1] += (Da * g) * (xm * yz);
-              part[4 * mm + 2] += (Db * g) * (ym * xz);
-              part[4 * mm + 3] += (Dc * g) * (zm * xy);
+            for (int m0 = 0; m0 < BATCH; m0 += MC) {
+              double g[MC], gd[MC], xm[MC], xa[MC], ym[MC], yb[MC], zm[MC], zc[MC];
+#pragma unroll
+              for (int u = 0; u < MC; u++) {
+                const int o = (b * BATCH + m0 + u) * NG;   // column offset of this lane's neighbour
+                g[u] = lds_ld(pg[t], o);
+                gd[u] = lds_ld(pd[t], o);
+                xm[u] = lds_ld(px[t], o);
+                xa[u] = lds_ld(px[t], PITCH + o);
+                ym[u] = lds_ld(py[t], o);
+                yb[u] = lds_ld(py[t], PITCH + o);
+                zm[u] = lds_ld(pz[t], o);
+                zc[u] = lds_ld(pz[t], PITCH + o);
+              }
+              __builtin_amdgcn_sched_barrier(0);   // the whole burst issues before its math
+#pragma unroll
+              for (int u = 0; u < MC; u++) {
+                const int mm = m0 + u;
+                const double yz = yb[u] * zc[u], xz = xa[u] * zc[u], xy = xa[u] * yb[u];
+                part[4 * mm + 0] += (Dk * gd[u]) * (xa[u] * yz);
+                part[4 * mm + 1] += (Da * g[u]) * (xm[u] * yz);
+                part[4 * mm + 2] += (Db * g[u]) * (ym[u] * xz);
+                part[4 * mm + 3] += (Dc * g[u]) * (zm[u] * xy);
+              }
+              if (m0 + MC < BATCH) __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);   // one basic's reads in flight at a time (register pressure)
           }
@@ -533,9 +568,13 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
             const double Fy = sr * ry + rq[2];
             const double Fz = sr * rz + rq[3];
             const size_t j = (size_t) w.nbj[n];
+#ifndef MTP_EXP_NOSCATTER   // timing experiment only (wrong results)
             unsafeAtomicAdd(&p.f[3 * j + 0], -Fx);   // pair_mtp.cpp:252-254
             unsafeAtomicAdd(&p.f[3 * j + 1], -Fy);
             unsafeAtomicAdd(&p.f[3 * j + 2], -Fz);
+#else
+            if (Fx + Fy + Fz == 12345.678) p.f[3 * j] = Fx;   // keeps the values live
+#endif
             fi0 += Fx;
             fi1 += Fy;
             fi2 += Fz;

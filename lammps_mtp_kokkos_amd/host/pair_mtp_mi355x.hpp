@@ -1,0 +1,119 @@
+// Host-side mirror of the reference's pair-style interface, above the C ABI
+// (include/mtp_mi355x.h), for callers that are not LAMMPS: same method names, argument
+// grammar and error text as LAMMPS_NS::PairMTP / PairMTPExtrapolation
+// (/root/reference/LAMMPS/ML-MTP/pair_mtp.h:34-40, pair_mtp_extrapolation.h:35-38).
+// Where LAMMPS would call error->all/one, these throw mtp_mi355x::Error with the same
+// message.  The LAMMPS plugin adapter (lammps_plugin/) is the same logic behind a real
+// `Pair` subclass.
+#pragma once
+
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mtp_mi355x.h"
+
+namespace mtp_mi355x {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+// What the pair style reads from LAMMPS each step (pair_mtp.cpp:77-85): plain pointers, no ownership.
+struct AtomView {
+  const double *x = nullptr;   // [nall][3]
+  double *f = nullptr;         // [nall][3], accumulated
+  const int *type = nullptr;   // [nall], 1-based
+  int nlocal = 0, nall = 0;
+  long natoms = 0;             // global atom count (atom->natoms)
+};
+struct NeighListView {
+  int inum = 0;
+  const int *ilist = nullptr;
+  const int *numneigh = nullptr;
+  const int *const *firstneigh = nullptr;
+};
+struct BoxView {   // domain->xprd ... for the .cfg writer (pair_mtp_extrapolation.cpp:449-451)
+  double xprd = 0, yprd = 0, zprd = 0, xy = 0, xz = 0, yz = 0;
+};
+// cross-rank reductions (LAMMPS: MPI_Allreduce on `world`); identity when unset (one rank)
+struct Reductions {
+  void (*sum)(double *buf, int n, void *ctx) = nullptr;
+  void (*max)(double *buf, int n, void *ctx) = nullptr;
+  void *ctx = nullptr;
+  int me = 0, nprocs = 1;
+};
+
+// pair_style mtp <file>            (pair_mtp.cpp:285-297)
+// pair_style mtp/kk <file> chunksize <N>, mtp/small/kk ... (KOKKOS/pair_mtp_kokkos.cpp:108-117):
+// the chunk size only bounded the reference's spilled Jacobian; it is parsed and ignored.
+class PairMTP {
+ public:
+  enum Style { MTP, MTP_KK, MTP_SMALL_KK };
+  explicit PairMTP(Style style = MTP, int device = 0);
+  virtual ~PairMTP();
+  PairMTP(const PairMTP &) = delete;
+  PairMTP &operator=(const PairMTP &) = delete;
+
+  virtual void settings(int narg, char **arg);
+  void coeff(int narg, char **arg);     // only "pair_coeff * *" (pair_mtp.cpp:303-307)
+  void init_style(int newton_pair);     // needs newton_pair on, full list (pair_mtp.cpp:313-319)
+  double init_one(int i, int j);        // returns the cutoff (pair_mtp.cpp:325-330)
+  virtual void compute(int eflag, int vflag);
+
+  // bindings in place of the LAMMPS pointers
+  void bind(const AtomView &a) { atom = a; }
+  void set_neighbor_list(const NeighListView &l);   // call after every re-neighbouring
+
+  // what LAMMPS reads back (pair.h)
+  double eng_vdwl = 0.0, virial[6] = {0, 0, 0, 0, 0, 0};
+  std::vector<double> eatom, vatom;   // [nall], [nall][6]; filled when the flags ask
+  int single_enable = 0, restartinfo = 0, one_coeff = 1, manybody_flag = 1;   // pair_mtp.cpp:37-40
+  mtp_potential_info info{};
+
+ protected:
+  void ev_setup(int eflag, int vflag);
+  void require(int rc, const char *what);
+  void load(const char *file, bool selection);
+  Style style_;
+  int device_;
+  mtp_potential *pot_ = nullptr;
+  mtp_context *ctx_ = nullptr;
+  AtomView atom;
+  bool list_set_ = false;
+  int eflag_either = 0, eflag_global = 0, eflag_atom = 0, vflag_either = 0, vflag_global = 0, vflag_atom = 0;
+};
+
+// pair_style mtp/extrapolation <file> [<out> <select> <break>] [chunksize <N>]
+// (pair_mtp_extrapolation.cpp:485-523)
+class PairMTPExtrapolation : public PairMTP {
+ public:
+  explicit PairMTPExtrapolation(Style style = MTP, int device = 0);
+  ~PairMTPExtrapolation() override;
+  void settings(int narg, char **arg) override;
+  void compute(int eflag, int vflag) override;
+  void *extract(const char *str, int &dim);           // "extrapolation_flag" (:624-631)
+  void *extract_peratom(const char *str, int &ncol);  // "extrapolation" (:641-652)
+  void set_reductions(const Reductions &r) { red = r; }
+  void set_box(const BoxView &b) { box = b; }
+
+  int nextra = 1;
+  double pvector[1] = {0.0};    // max grade, rank 0 only (:381)
+  int extrapolation_flag = 0;   // set by `fix pair` through extract()
+  double max_grade = 0.0;
+
+ private:
+  void compile_grades();     // :363-382
+  void evaluate_grades();    // :387-397
+  void write_config();       // :401-479
+  bool mlip3_style = false, configuration_mode = false;
+  double select_threshold = 0, break_threshold = 0;
+  std::FILE *preselected_file = nullptr;
+  std::vector<double> nbh_extrapolation_grades, energy_ders_wrt_coeffs;
+  Reductions red;
+  BoxView box;
+};
+
+}   // namespace mtp_mi355x

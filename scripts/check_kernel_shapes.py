@@ -21,9 +21,11 @@ def run(c):
                         "-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c", f, "-o", f + ".o"],
                        capture_output=True, text=True)
     out = r.stderr
-    v = re.findall(r"VGPRs: (\d+)", out)
-    sp = re.findall(r"VGPRs Spill: (\d+)", out)
-    return c, ("ERR" if "error" in out else "ok"), v[-1] if v else None, sp[-1] if sp else None
+    res = []
+    for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?VGPRs Spill: (\d+)", out, re.S):
+        if "mtp_wave_kernel" in m.group(1):
+            res.append(("grade" if "ELb1E" in m.group(1) else "force", int(m.group(2)), int(m.group(3))))
+    return c, ("ERR" if "error" in out else "ok"), res
 
 
 with concurrent.futures.ThreadPoolExecutor(6) as ex:

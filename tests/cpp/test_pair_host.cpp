@@ -1,0 +1,198 @@
+// Driver for the C++ host mirror (lammps_mtp_kokkos_amd/host): the call sequence LAMMPS makes
+// on a pair style -- settings, coeff, init_style, init_one, compute -- on a system read from a
+// text file written by tests/test_pair_host.py.
+//
+//   test_pair_host args                                   argument-grammar checks (no GPU needed)
+//   test_pair_host run    <style> <system> <out> <pair_style args...>
+//   test_pair_host runext <style> <system> <out> <pair_style args...>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../lammps_mtp_kokkos_amd/host/pair_mtp_mi355x.hpp"
+
+using namespace mtp_mi355x;
+
+struct System {
+  int nlocal = 0, nall = 0;
+  std::vector<double> x, f;
+  std::vector<int> type, ilist, numneigh;
+  std::vector<std::vector<int>> rows;
+  std::vector<const int *> firstneigh;
+  double box[3] = {0, 0, 0};
+  void read(const char *path)
+  {
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error(std::string("cannot open ") + path);
+    in >> nlocal >> nall >> box[0] >> box[1] >> box[2];
+    x.resize(3 * (size_t) nall);
+    type.resize(nall);
+    for (int i = 0; i < nall; i++) in >> x[3 * i] >> x[3 * i + 1] >> x[3 * i + 2] >> type[i];
+    numneigh.assign(nall, 0);
+    rows.assign(nall, {});
+    for (int i = 0; i < nlocal; i++) {
+      int n;
+      in >> n;
+      numneigh[i] = n;
+      rows[i].resize(n);
+      for (int k = 0; k < n; k++) in >> rows[i][k];
+      ilist.push_back(i);
+    }
+    firstneigh.resize(nall);
+    for (int i = 0; i < nall; i++) firstneigh[i] = rows[i].data();
+    f.assign(3 * (size_t) nall, 0.0);
+  }
+};
+
+
+static PairMTP::Style style_of(const std::string &s)
+{
+  if (s == "mtp" || s == "mtp/extrapolation") return PairMTP::MTP;
+  if (s == "mtp/kk" || s == "mtp/extrapolation/kk") return PairMTP::MTP_KK;
+  if (s == "mtp/small/kk" || s == "mtp/extrapolation/small/kk") return PairMTP::MTP_SMALL_KK;
+  throw std::runtime_error("unknown style " + s);
+}
+
+template <class F> static bool throws(F &&fn, const char *needle)
+{
+  try {
+    fn();
+  } catch (const Error &e) {
+    if (std::strstr(e.what(), needle)) return true;
+    std::printf("unexpected message: %s\n", e.what());
+    return false;
+  }
+  std::printf("no exception, expected: %s\n", needle);
+  return false;
+}
+
+static int check_args(const char *l8, const char *nbh)
+{
+  int bad = 0;
+  char a0[512], a1[] = "chunksize", a2[] = "32768", a3[] = "oops", a4[] = "out.cfg", a5[] = "2.0", a6[] = "10.0";
+  std::snprintf(a0, sizeof(a0), "%s", l8);
+  {   // pair_style mtp: one argument; extras are ignored (pair_mtp.cpp:285-297)
+    PairMTP p;
+    char *none[1] = {nullptr};
+    bad += !throws([&] { p.settings(0, none); }, "only accepts 1 argument");
+    char *two[2] = {a0, a3};
+    p.settings(2, two);
+    bad += p.info.alpha_index_basic_count != 11;
+    char *c2[2] = {a3, a3};
+    p.coeff(2, c2);
+    bad += !throws([&] { p.coeff(3, c2); }, "Only \"pair_coeff * *\" is permitted");
+    bad += p.init_one(1, 1) != 5.0;
+    bad += !throws([&] { p.init_one(1, 2); }, "Not all pair coeffs are set. See types 1-2.");
+    bad += !throws([&] { p.init_style(0); }, "requires Newton Pair on");
+  }
+  {   // mtp/kk: exactly <file> chunksize <N> (KOKKOS/pair_mtp_kokkos.cpp:113-117)
+    PairMTP p(PairMTP::MTP_KK);
+    char *one[1] = {a0};
+    bad += !throws([&] { p.settings(1, one); }, "requires 3 arguments");
+    char *wrong[3] = {a0, a3, a2};
+    bad += !throws([&] { p.settings(3, wrong); }, "requires 3 arguments");
+    char *ok[3] = {a0, a1, a2};
+    p.settings(3, ok);
+  }
+  {   // mtp/extrapolation: 1 or 4 arguments, optional trailing chunksize pair (pair_mtp_extrapolation.cpp:488-502)
+    std::snprintf(a0, sizeof(a0), "%s", nbh);
+    PairMTPExtrapolation p;
+    char *two[2] = {a0, a4};
+    bad += !throws([&] { p.settings(2, two); }, "only accepts 1 argument");
+    char *three[3] = {a0, a1, a2};
+    p.settings(3, three);
+    char *six[6] = {a0, a4, a5, a6, a1, a2};
+    p.settings(6, six);
+    int dim = -1, ncol = -1;
+    bad += p.extract("extrapolation_flag", dim) != (void *) &p.extrapolation_flag || dim != 0;
+    bad += p.extract("nope", dim) != nullptr;
+    bad += p.extract_peratom("nope", ncol) != nullptr;
+    char *badnum[4] = {a0, a4, a3, a6};
+    bad += !throws([&] { p.settings(4, badnum); }, "Expected floating point parameter");
+    std::snprintf(a0, sizeof(a0), "%s", l8);   // a plain .mtp has no selection state
+    char *one[1] = {a0};
+    bad += !throws([&] { p.settings(1, one); }, "No selection state found");
+  }
+  std::remove("out.cfg");
+  std::printf(bad ? "ARGS FAILED %d\n" : "ARGS OK\n", bad);
+  return bad;
+}
+
+int main(int argc, char **argv)
+{
+  try {
+    if (argc >= 4 && !std::strcmp(argv[1], "args")) return check_args(argv[2], argv[3]);
+    if (argc < 6) {
+      std::fprintf(stderr, "usage: see the header of this file\n");
+      return 2;
+    }
+    const bool ext = !std::strcmp(argv[1], "runext");
+    System s;
+    s.read(argv[3]);
+    AtomView av;
+    av.x = s.x.data();
+    av.f = s.f.data();
+    av.type = s.type.data();
+    av.nlocal = s.nlocal;
+    av.nall = s.nall;
+    av.natoms = s.nlocal;
+    NeighListView lv{s.nlocal, s.ilist.data(), s.numneigh.data(), s.firstneigh.data()};
+    char star[] = "*";
+    char *cf[2] = {star, star};
+    std::ofstream out(argv[4]);
+    out.precision(17);
+    if (!ext) {
+      PairMTP p(style_of(argv[2]));
+      p.settings(argc - 5, argv + 5);
+      p.coeff(2, cf);
+      p.bind(av);
+      p.init_style(1);
+      double cut = p.init_one(1, 1);
+      p.set_neighbor_list(lv);
+      p.compute(3, 4);
+      out << p.eng_vdwl << " " << cut << "\n";
+      for (int q = 0; q < 6; q++) out << p.virial[q] << (q == 5 ? "\n" : " ");
+      for (int i = 0; i < s.nall; i++)
+        out << s.f[3 * i] << " " << s.f[3 * i + 1] << " " << s.f[3 * i + 2] << " " << p.eatom[i] << "\n";
+    } else {
+      PairMTPExtrapolation p(style_of(argv[2]));
+      p.settings(argc - 5, argv + 5);
+      p.coeff(2, cf);
+      p.bind(av);
+      BoxView b;
+      b.xprd = s.box[0];
+      b.yprd = s.box[1];
+      b.zprd = s.box[2];
+      p.set_box(b);
+      p.init_style(1);
+      p.set_neighbor_list(lv);
+      int dim = 0, ncol = 0;
+      // no grade requested: plain forces (pair_mtp_extrapolation.cpp:71-74) unless MLIP-3 style
+      p.compute(3, 0);
+      const double e_plain = p.eng_vdwl;
+      std::fill(s.f.begin(), s.f.end(), 0.0);
+      *(int *) p.extract("extrapolation_flag", dim) = 1;   // what `fix pair` does
+      bool stopped = false;
+      std::string why;
+      try {
+        p.compute(3, 0);
+      } catch (const Error &e) {
+        stopped = true;
+        why = e.what();
+      }
+      out << p.eng_vdwl << " " << e_plain << " " << p.pvector[0] << " " << (stopped ? 1 : 0) << "\n";
+      if (!p.info.configuration_mode) {
+        const double *g = (const double *) p.extract_peratom("extrapolation", ncol);
+        for (int i = 0; i < s.nlocal; i++) out << g[i] << "\n";
+      }
+      if (stopped) std::printf("stopped: %s", why.c_str());
+    }
+    return 0;
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "ERROR: %s\n", e.what());
+    return 1;
+  }
+}

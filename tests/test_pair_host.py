@@ -1,0 +1,98 @@
+"""The C++ host mirror of the reference's Pair interface (lammps_mtp_kokkos_amd/host), driven
+through the call sequence LAMMPS uses: settings -> coeff -> init_style -> init_one -> compute,
+plus extract / extract_peratom / pvector for the extrapolation style."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from lammps_mtp_kokkos_amd import mtpgen
+from lammps_mtp_kokkos_amd.driver import periodic_system
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+POT = os.path.join(ROOT, "potentials")
+EXE = os.path.join(ROOT, "tests", "cpp", "test_pair_host")
+
+
+def _build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "lammps_mtp_kokkos_amd", "host")])
+
+
+def _write_system(path, s):
+    with open(path, "w") as fh:
+        fh.write("%d %d %.17g %.17g %.17g\n" % (s.nlocal, s.nall, *s.box))
+        for (x, y, z), t in zip(s.x, s.types):
+            fh.write("%.17g %.17g %.17g %d\n" % (x, y, z, t))
+        for i in range(s.nlocal):
+            row = s.neigh[s.first[i]:s.first[i + 1]]
+            fh.write("%d %s\n" % (len(row), " ".join(map(str, row))))
+
+
+def test_argument_grammar_and_errors():
+    _build()
+    out = subprocess.run([EXE, "args", os.path.join(POT, "W_L8.mtp"), os.path.join(POT, "W_L16_nbh.almtp")],
+                         capture_output=True, text=True, cwd=str(ROOT))
+    assert out.returncode == 0 and "ARGS OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("style,extra", [("mtp", []), ("mtp/kk", ["chunksize", "32768"]),
+                                         ("mtp/small/kk", ["chunksize", "4096"])])
+def test_pair_styles_match_oracle(tmp_path, style, extra):
+    from oracle.pyoracle import Oracle
+    _build()
+    pos, box = mtpgen.bcc_lattice(4, 4, 4)
+    s = periodic_system(pos, box, None, 7.0)
+    sysf, outf = str(tmp_path / "sys.txt"), str(tmp_path / "out.txt")
+    _write_system(sysf, s)
+    potf = os.path.join(POT, "W_L16.mtp")
+    r = subprocess.run([EXE, "run", style, sysf, outf, potf] + extra, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = open(outf).read().split("\n")
+    e, cut = map(float, lines[0].split())
+    vir = np.array(lines[1].split(), float)
+    arr = np.array([l.split() for l in lines[2:2 + s.nall]], float)
+    want = Oracle(potf).compute(s.x, s.types, s.ilist, s.first, s.neigh)
+    assert cut == 5.0
+    assert abs(e - want["energy"]) < 1e-9
+    assert np.abs(arr[:, :3] - want["f"]).max() < 1e-9
+    assert np.abs(arr[:, 3] - want["eatom"]).max() < 1e-10
+    assert np.abs(vir - want["virial"]).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_extrapolation_style_fix_pair_protocol_and_cfg_file(tmp_path):
+    from oracle.pyoracle import Oracle
+    _build()
+    pos, box = mtpgen.bcc_lattice(3, 3, 3)
+    s = periodic_system(pos, box, None, 7.0)
+    sysf, outf, cfgf = str(tmp_path / "sys.txt"), str(tmp_path / "out.txt"), str(tmp_path / "sel.cfg")
+    _write_system(sysf, s)
+    potf = os.path.join(POT, "W_L16_nbh.almtp")
+    want = Oracle(potf, selection=True).compute(s.x, s.types, s.ilist, s.first, s.neigh, extrapolation=True)
+    mg = want["max_grade"]
+    # select threshold below the max grade -> configuration written; break threshold above -> keeps running
+    r = subprocess.run([EXE, "runext", "mtp/extrapolation", sysf, outf, potf, cfgf, "%.6f" % (0.5 * mg), "%.6f" % (2 * mg)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = open(outf).read().split("\n")
+    e, e_plain, pv, stopped = lines[0].split()
+    assert abs(float(e) - want["energy"]) < 1e-9 and abs(float(e_plain) - want["energy"]) < 1e-9
+    assert abs(float(pv) - mg) < 1e-9 * max(1, mg) and stopped == "0"
+    g = np.array(lines[1:1 + s.nlocal], float)
+    assert np.abs(g - want["grades"][: s.nlocal]).max() < 1e-9 * max(1, mg)
+    cfg = open(cfgf).read()
+    # MLIP-3 style grades every call: two compute calls -> two records (pair_mtp_extrapolation.cpp:71, 341)
+    assert cfg.count("BEGIN_CFG") == 2 and cfg.count("END_CFG") == 2
+    rec = cfg.split("END_CFG")[0].split("\n")
+    assert rec[0] == "BEGIN_CFG" and rec[1] == "Size" and int(rec[2]) == s.nlocal and rec[3] == "Supercell"
+    assert rec[4] == "%.6f %.6f %.6f" % (s.box[0], 0, 0)
+    assert rec[7].startswith("AtomData:  id type       cartes_x") and rec[7].endswith("nbh_grades")
+    first = rec[8].split("\t")
+    assert first[0] == "1" and first[1] == "0" and first[5] == "%.5f" % want["grades"][0]
+    assert any(l.startswith("Feature   MV_grade\t%.6f" % mg) for l in rec)
+    # break threshold below the max grade -> the run is terminated with the reference's message
+    r = subprocess.run([EXE, "runext", "mtp/extrapolation", sysf, outf, potf, cfgf, "%.6f" % (0.5 * mg), "%.6f" % (0.9 * mg)],
+                       capture_output=True, text=True)
+    assert "Exceeded Break Threshold" in r.stdout + r.stderr
