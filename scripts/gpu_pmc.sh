@@ -17,6 +17,7 @@ run tcc2 WRITE_SIZE
 run tcc3 TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum
 python - <<PY
 import csv, glob, collections
+tot = {}
 for name in ["sq1","sq2","sq3","tcc1","tcc2","tcc3"]:
     files = glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True)
     acc = collections.defaultdict(list)
@@ -26,4 +27,15 @@ for name in ["sq1","sq2","sq3","tcc1","tcc2","tcc3"]:
                 acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k,v in acc.items():
         print("%s %-28s mean per launch %.6g  (n=%d)" % (name, k, sum(v)/len(v), len(v)))
+        tot[k] = sum(v)/len(v)
+import json
+if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+    json.dump({"hbm_bytes_per_launch": (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024,
+               "fetch_kb": tot["FETCH_SIZE"], "write_kb": tot["WRITE_SIZE"],
+               "fetch_doubled_bound_bytes": (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024,
+               "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes, per launch of mtp_wave_kernel "
+                       "(bench.py, 65,536 atoms level 16). FETCH_SIZE is taken as reported: the guide's x2 correction "
+                       "is calibrated for 16 B/lane streams only, these reads are 4-8 B gathers (uncalibrated); "
+                       "fetch_doubled_bound_bytes applies the x2 as an upper bound. WRITE_SIZE is exact for atomics."},
+              open("$OUT/pmc_traffic.json", "w"), indent=1)
 PY
