@@ -84,7 +84,8 @@ struct mtp_context {
   struct LaunchPlan {
     int wpb = 1, grid = 1, wave_doubles = 0, tab_rows = 0, g_doubles = 0, m_doubles = 0;
     size_t lds_bytes = 0;
-  } lp[2];   // [0] force calls, [1] grade calls
+  } lp[3];   // [0] force calls (wavefront per atom), [1] grade calls, [2] force calls (workgroup per atom)
+  bool use_team = false;
   DevBuf<double> d_cvec, d_ainv_pad;
   int cpad = 0;
   // timing
@@ -148,6 +149,32 @@ void mtp_context::plan()
     const int blocks_per_cu = std::max(1, best / best_w);
     const int need = (inum + best_w - 1) / best_w;
     L.grid = std::max(1, std::min(need, num_cus * blocks_per_cu));
+  }
+  {   // workgroup-per-atom plan: 4 wavefronts share one atom's LDS image; 128 VGPRs -> up to 4 workgroups per CU
+    LaunchPlan &L = lp[2];
+    int TKL = 16, TKBW = 1;
+    const bool ok = mtp_pick_team_shape(p.alpha_index_basic_count, &TKL, &TKBW) == 0;
+    L.tab_rows = 2 * p.slot_count + 3 * P;
+    L.g_doubles = 0;
+    L.m_doubles = std::max(std::max(A, 4 * TKL * TKBW * 4), 144);
+    const size_t dbl = (size_t) A + L.m_doubles + (size_t) L.tab_rows * (nt + 2) + 5 * (size_t) nt + 4 * 64;
+    const size_t ints = (size_t) 2 * nt + 8 + cap;
+    const size_t wb = (dbl * 8 + ints * 4 + 15) / 16 * 16;
+    const size_t blk = blob + wb;
+    int per_cu = ok && blk <= LDS ? std::min<int>(4, (int) (LDS / blk)) : 0;
+    if (const char *e = std::getenv("MTP_TEAM_PER_CU")) {   // tuning override (benchmarks only)
+      int v = std::atoi(e);
+      if (v >= 1 && v <= 8 && (size_t) v * blk <= LDS) per_cu = v;
+    }
+    L.wpb = 4;
+    L.wave_doubles = (int) (wb / 8);
+    L.lds_bytes = blk;
+    L.grid = per_cu > 0 ? std::max(1, std::min(inum, num_cus * per_cu)) : 0;
+    // Experimental: measured SLOWER than the wavefront-per-atom kernel at every size tried on MI355X
+    // (65,536 atoms: 1.63 vs 1.08 ms; 1,024 atoms: 51 vs 32 us) -- the per-atom chain of dependent LDS
+    // round trips does not shrink with more wavefronts, and barriers are added.  Only MTP_TEAM=1 selects it.
+    use_team = false;
+    if (const char *e = std::getenv("MTP_TEAM")) use_team = L.grid > 0 && std::atoi(e) != 0;
   }
   base.NT = nt;
   base.cj_cap = cap;
@@ -507,7 +534,8 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
   p.eflag = eflag;
   p.vflag = vflag;
   p.grade_flag = grade_flag ? 1 : 0;
-  const mtp_context::LaunchPlan &L = c->lp[grade_flag ? 1 : 0];
+  const bool team = !grade_flag && c->use_team;
+  const mtp_context::LaunchPlan &L = c->lp[grade_flag ? 1 : (team ? 2 : 0)];
   p.tab_rows = L.tab_rows;
   p.g_doubles = L.g_doubles;
   p.m_doubles = L.m_doubles;
@@ -522,7 +550,8 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
       }
       HIP_CHECK(hipEventRecord(c->ev0, st));
     }
-    HIP_CHECK(mtp_launch_wave_kernel(p, L.grid, L.wpb, L.lds_bytes, st));
+    if (team) HIP_CHECK(mtp_launch_team_kernel(p, L.grid, L.lds_bytes, st));
+    else HIP_CHECK(mtp_launch_wave_kernel(p, L.grid, L.wpb, L.lds_bytes, st));
     if (c->timing) {
       HIP_CHECK(hipEventRecord(c->ev1, st));
       c->timed = true;
@@ -632,9 +661,10 @@ int mtp_context_launch_info(const mtp_context *c, int32_t *lds_bytes_per_wave, i
                             int32_t *grid_blocks, int32_t *neighbor_tile)
 {
   if (!c || !c->have_list) return MTP_ERR_STATE;
-  if (lds_bytes_per_wave) *lds_bytes_per_wave = c->lp[0].wave_doubles * 8;
-  if (waves_per_block) *waves_per_block = c->lp[0].wpb;
-  if (grid_blocks) *grid_blocks = c->lp[0].grid;
+  const mtp_context::LaunchPlan &L = c->lp[c->use_team ? 2 : 0];
+  if (lds_bytes_per_wave) *lds_bytes_per_wave = L.wave_doubles * 8;   // per atom image
+  if (waves_per_block) *waves_per_block = c->use_team ? -L.wpb : L.wpb;   // negative: wavefronts per ATOM
+  if (grid_blocks) *grid_blocks = L.grid;
   if (neighbor_tile) *neighbor_tile = c->base.NT;
   return MTP_OK;
 }

@@ -63,6 +63,9 @@ struct MtpDevParams {
 // lane-grid shape for B basics: KL k-lanes x KB basics per lane; -1 when B is too large
 int mtp_pick_shape(int B, int *KL, int *KB);
 hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);
+// workgroup-per-atom variant (4 wavefronts per atom); force calls only
+int mtp_pick_team_shape(int B, int *KL, int *KBW);
+hipError_t mtp_launch_team_kernel(const MtpDevParams &p, int grid, size_t lds, hipStream_t st);
 hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st);
 // grades[ilist[ii]] = max_r |sum_c cvec[ii][c] Ainv[r][c]| (f64 MFMA), running maximum into max_grade
 hipError_t mtp_launch_grade_kernel(const double *cvec, const double *ainv_pad, int cpad, int C, int inum,

@@ -33,96 +33,9 @@
 
 #include "mtp_device.hpp"
 
-#define MTP_NEIGHMASK 0x1FFFFFFF   // LAMMPS NEIGHMASK (pair_mtp.cpp:114)
-
-// Diagnostic build only (make stamps): per-phase s_memtime sums per launch into p.stamps[16].
-// The shipped library is built without MTP_STAMPS and executes no stamp.
-#ifdef MTP_STAMPS
-#define STAMP(k)                                                         \
-  do {                                                                   \
-    const unsigned long long _t = __builtin_amdgcn_s_memtime();          \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                  \
-    st_acc[k] += _t - st_prev;                                           \
-    st_prev = _t;                                                        \
-  } while (0)
-#else
-#define STAMP(k) ((void) 0)
-#endif
+#include "mtp_kernel_common.hpp"
 
 namespace {
-
-__device__ __forceinline__ void wave_fence()
-{
-  // LDS operations of one wavefront execute in program order; this only stops the
-  // compiler from moving LDS accesses across a phase boundary.
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
-
-__device__ __forceinline__ double uniform_f64(double v)   // v is wave-uniform: move it to SGPRs
-{
-  const long long b = __double_as_longlong(v);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) b);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned) (b >> 32));
-  return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
-}
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) v += shfl_xor_f64(v, s);
-  return v;
-}
-
-__device__ __forceinline__ void lds_add(double *p, double v)
-{
-#ifdef MTP_EXP_NOATOM   // timing experiment only (wrong results): plain store instead of ds_add_f64
-  *(volatile double *) p = v;
-#else
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-}
-
-// LDS read at (32-bit LDS byte address + compile-time byte offset): the offset lands in the
-// ds_read immediate field, so inner loops spend no VALU on addressing.
-typedef __attribute__((address_space(3))) const double lds_cdouble;
-// (no generic -> LDS pointer casts: hipcc 7.2 miscompiles their null check on gfx950; LDS byte
-// addresses are formed as the LDS address of the dynamic array + an offset instead)
-// volatile: hipcc otherwise fuses neighbouring reads into ds_read2_b64, which moves 16 B per lane in
-// 8 LDS cycles where two ds_read_b64 take 4 (MI355X_MICROARCH.md, LDS table)
-__device__ __forceinline__ double lds_ld(unsigned base, int off_doubles)   // off: constant after unrolling
-{
-  return *(volatile lds_cdouble *) (size_t) (base + 8u * (unsigned) off_doubles);
-}
-
-// Butterfly transpose-reduce over the lane bits below N: every lane enters with N partial
-// sums v[0..N); on exit v[0] of lane l holds entry (l mod N) summed over the N lanes that
-// differ from l only in those bits.  N-1 adds and N-1 exchanges instead of N*log2(N).
-template <int N> struct Butterfly {
-  static __device__ __forceinline__ void run(double *v, int lane)
-  {
-    constexpr int H = N / 2;
-    const bool hi = (lane & H) != 0;
-#pragma unroll
-    for (int i = 0; i < H; i++) {
-      const double keep = hi ? v[i + H] : v[i];
-      const double send = hi ? v[i] : v[i + H];
-      v[i] = keep + shfl_xor_f64(send, H);
-    }
-    Butterfly<H>::run(v, lane);
-  }
-};
-template <> struct Butterfly<1> {
-  static __device__ __forceinline__ void run(double *, int) {}
-};
-
-struct BlockTables {   // views into the workgroup-shared head of LDS
-  const MtpRow8 *rows;
-  const int *level, *slot, *seed_idx, *map, *pack;
-  const double *radial, *seed_val, *lin;
-};
 
 template <int PITCH> struct WaveLds {
   static constexpr int NT = PITCH - 2;
