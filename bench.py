@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--cells", type=int, default=32, help="BCC cells per edge (32 -> 65,536 atoms)")
     ap.add_argument("--potential", default=os.path.join(ROOT, "potentials", "W_L16.mtp"))
     ap.add_argument("--variant", default="auto", choices=["auto", "large", "small"])
+    ap.add_argument("--workload", default="w16", choices=["w16", "small2k", "wre20", "grades"],
+                    help="w16: BASELINE configs[1] (default); small2k: configs[2]; wre20: level-20 W-Re shard of "
+                         "configs[3]; grades: configs[4] (MaxVol neighbourhood grades every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -57,6 +60,22 @@ def main():
     from lammps_mtp_kokkos_amd import capi, mtpgen
     from lammps_mtp_kokkos_amd.domain import HaloExchange, decompose
 
+    # BASELINE.json configs other than the headline one (the default is untouched by these)
+    cells3 = (args.cells,) * 3
+    species, grade, metric_name = 1, False, "atom-steps/s (64k-atom W, level-16 MTP)"
+    if args.workload == "small2k":
+        cells3 = (8, 8, 16)
+        args.variant = "small" if args.variant == "auto" else args.variant
+        metric_name = "atom-steps/s (2,048-atom W, level-16 MTP, small variant)"
+    elif args.workload == "wre20":
+        args.potential = os.path.join(ROOT, "potentials", "WRe_L20.mtp")
+        species = 2
+        metric_name = "atom-steps/s (W-Re 10%% Re, level-20 MTP, %d^3 cells)" % args.cells
+    elif args.workload == "grades":
+        args.potential = os.path.join(ROOT, "potentials", "W_L16_nbh.almtp")
+        grade = True
+        metric_name = "atom-steps/s (64k-atom W, level-16 MTP, MaxVol neighbourhood grades every step)"
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -65,20 +84,28 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("MTP_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of N > 1 on a single GPU
+    devidx = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(devidx)
+    dev = torch.device("cuda", devidx)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- synthetic workload --------------------------------------------------
-    pos, box = mtpgen.bcc_lattice(args.cells, args.cells, args.cells, a=3.165, jitter=0.05, seed=777)
+    pos, box = mtpgen.bcc_lattice(*cells3, a=3.165, jitter=0.05, seed=777)
     natoms = len(pos)
     list_cutoff = 7.0
-    plan = decompose(pos, box, None, world, rank, list_cutoff)
-    pot = capi.Potential(args.potential)
+    gtypes = None
+    if species == 2:   # W + 10 % Re, seeded
+        gtypes = (np.random.default_rng(4242).random(natoms) < 0.10).astype(np.int32) + 1
+    plan = decompose(pos, box, gtypes, world, rank, list_cutoff)
+    pot = capi.Potential(args.potential, selection=grade)
     sizes = pot.sizes
-    ctx = capi.Context(pot, local_rank)
+    ctx = capi.Context(pot, devidx)
     ctx.set_variant(dict(auto=0, large=1, small=2)[args.variant])
     il = torch.from_numpy(plan.ilist).to(dev)
     fi = torch.from_numpy(plan.first).to(dev)
@@ -92,12 +119,15 @@ def main():
     halo = HaloExchange(plan, dev)
     stream = torch.cuda.current_stream().cuda_stream
     EFLAG, VFLAG = 1, 1
+    grades_t = torch.zeros(plan.nall, dtype=torch.float64, device=dev) if grade else None
+    maxg_t = torch.zeros(1, dtype=torch.float64, device=dev) if grade else None
 
     def step():
         f.zero_()
         if world > 1:
             halo.forward(x)
-        ctx.compute_device(x, ty, f, eflag=EFLAG, vflag=VFLAG, ev_t=ev, stream=stream)
+        ctx.compute_device(x, ty, f, eflag=EFLAG, vflag=VFLAG, ev_t=ev, stream=stream, grade=grade,
+                           grades_t=grades_t, maxg_t=maxg_t)
         if world > 1:
             halo.reverse(f)
 
@@ -129,7 +159,8 @@ def main():
     kms = []
     for _ in range(min(args.steps, 50)):
         f.zero_()
-        ctx.compute_device(x, ty, f, eflag=EFLAG, vflag=VFLAG, ev_t=ev, stream=stream)
+        ctx.compute_device(x, ty, f, eflag=EFLAG, vflag=VFLAG, ev_t=ev, stream=stream, grade=grade,
+                           grades_t=grades_t, maxg_t=maxg_t)
         kms.append(ctx.last_kernel_ms())
     ctx.set_timing(False)
     kernel_ms = float(np.mean(kms))
@@ -155,7 +186,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.pyoracle import Oracle
-        o = Oracle(args.potential)
+        o = Oracle(args.potential, selection=grade)
         xs = plan.x0
         nsub = min(plan.nlocal, 16384)
         sub_first = plan.first[: nsub + 1]
@@ -163,7 +194,8 @@ def main():
         passes, tcpu = 0, 0.0
         while tcpu < args.cpu_seconds and passes < 50:
             c0 = time.perf_counter()
-            rc = o.compute(xs, plan.types, plan.ilist[:nsub], sub_first, sub_neigh, eflag=EFLAG, vflag=VFLAG)
+            rc = o.compute(xs, plan.types, plan.ilist[:nsub], sub_first, sub_neigh, eflag=EFLAG, vflag=VFLAG,
+                           extrapolation=grade)
             tcpu += time.perf_counter() - c0
             passes += 1
         cpu = {"value": nsub * passes / tcpu, "unit": "atom-steps/s", "cores": 1, "kind": "port",
@@ -184,13 +216,15 @@ def main():
         value = natoms * args.steps / dt
         info = ctx.launch_info()
         line = {
-            "metric": "atom-steps/s (64k-atom W, level-16 MTP)", "value": value, "unit": "atom-steps/s",
+            "metric": metric_name, "value": value, "unit": "atom-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%d-atom BCC W (a=3.165 A, +-0.05 A jitter, seed 777), level-16 MTP "
-                                   "(B=%d T=%d S=%d A=%d R=%d Mu=%d), rc=5 A, full list 7 A, eflag=1 vflag=1"
-                                   % (natoms, sizes["B"], sizes["T"], sizes["S"], sizes["A"], sizes["R"], sizes["Mu"]),
+            "config": {"workload": "%d-atom BCC %s (a=3.165 A, +-0.05 A jitter, seed 777), %s "
+                                   "(B=%d T=%d S=%d A=%d R=%d Mu=%d C=%d), rc=5 A, full list 7 A, eflag=1 vflag=1%s"
+                                   % (natoms, "W" if species == 1 else "W-10%Re", os.path.basename(args.potential),
+                                      sizes["B"], sizes["T"], sizes["S"], sizes["A"], sizes["R"], sizes["Mu"], sizes["C"],
+                                      ", neighbourhood grades every step" if grade else ""),
                        "atoms": natoms, "potential": os.path.basename(args.potential),
                        "parallelism": "domain decomposition %s, RCCL all-to-all halo" % "x".join(map(str, plan.grid))
                        if world > 1 else "single GPU",

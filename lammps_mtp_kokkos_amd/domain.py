@@ -153,6 +153,12 @@ class HaloExchange:
         import torch.distributed as dist
         if self.single:
             out.copy_(inp)
+        elif inp.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal only (several ranks on one GPU): gloo has no device all-to-all, stage through the host
+            o = self.torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits,
+                                   group=self.group)
+            out.copy_(o)
         else:
             dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits,
                                    group=self.group)
