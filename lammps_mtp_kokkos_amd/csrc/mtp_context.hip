@@ -86,8 +86,8 @@ struct mtp_context {
     size_t lds_bytes = 0;
   } lp[3];   // [0] force calls (wavefront per atom), [1] grade calls, [2] force calls (workgroup per atom)
   bool use_team = false;
-  DevBuf<double> d_cvec, d_ainv_pad;
-  int cpad = 0;
+  DevBuf<double> d_cvec, d_ainv_pad, d_dbasic;
+  int cpad = 0, dpad = 0;
   // timing
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -111,12 +111,12 @@ void mtp_context::plan()
   const size_t LDS = 160 * 1024;
   const size_t blob = (size_t) base.blob_bytes;
   const int nt = 32;
-  for (int g = 0; g < 2; g++) {
-    LaunchPlan &L = lp[g];
-    L.tab_rows = 2 * p.slot_count + 3 * P + (g ? P + p.radial_basis_size : 0);
-    L.g_doubles = g ? p.radial_func_count * nt + p.species_count * p.radial_func_count * p.radial_basis_size : 0;
+  {   // [0] fused force kernel (also its grade instantiation, which only adds two HBM writes)
+    LaunchPlan &L = lp[0];
+    L.tab_rows = 2 * p.slot_count + 3 * P;
+    L.g_doubles = 0;
     L.m_doubles = std::max(std::max(A, 4 * KL * KB), 144);
-    const size_t dbl = (size_t) A + L.m_doubles + (size_t) L.tab_rows * (nt + 2) + 5 * (size_t) nt + 64 + L.g_doubles;
+    const size_t dbl = (size_t) A + L.m_doubles + (size_t) L.tab_rows * (nt + 2) + 5 * (size_t) nt + 64;
     const size_t ints = (size_t) 2 * nt + cap;
     const size_t wb = (dbl * 8 + ints * 4 + 15) / 16 * 16;
     // waves per CU for w waves per workgroup; registers allow 8 (2 per SIMD)
@@ -149,6 +149,23 @@ void mtp_context::plan()
     const int blocks_per_cu = std::max(1, best / best_w);
     const int need = (inum + best_w - 1) / best_w;
     L.grid = std::max(1, std::min(need, num_cus * blocks_per_cu));
+  }
+  {   // [1] candidate-vector kernel of grade calls: small table (r^-nu, Q_ri, powers), 8 wavefronts per workgroup
+    LaunchPlan &L = lp[1];
+    const int Mu = p.radial_func_count, R = p.radial_basis_size, Sp = p.species_count;
+    const size_t dbl = (size_t) KL * KB + (size_t) (4 * P + R) * (nt + 2) + 4 * (size_t) nt + (size_t) Mu * nt + (size_t) Sp * Mu * R;
+    const size_t ints = (size_t) nt + cap;
+    const size_t wb = (dbl * 8 + ints * 4 + 15) / 16 * 16;
+    int w = 8;
+    while (w > 1 && blob + w * wb > LDS) w--;
+    L.wpb = w;
+    L.wave_doubles = (int) (wb / 8);
+    L.lds_bytes = blob + wb * w;
+    const int blocks_per_cu = std::max<int>(1, std::min<int>(8 / w, (int) (LDS / L.lds_bytes)));
+    L.grid = std::max(1, std::min((inum + w - 1) / w, num_cus * blocks_per_cu));
+    L.tab_rows = 4 * P + R;
+    L.m_doubles = KL * KB;
+    L.g_doubles = 0;
   }
   {   // workgroup-per-atom plan: 4 wavefronts share one atom's LDS image; 128 VGPRs -> up to 4 workgroups per CU
     LaunchPlan &L = lp[2];
@@ -430,6 +447,10 @@ static int finish_list(mtp_context *c, int inum, int nall, int max_numneigh)
         c->d_cvec.reserve(n);
         HIP_CHECK(hipMemset(c->d_cvec.ptr, 0, n * sizeof(double)));
       }
+      int kl_ = 16, kb_ = 1;
+      (void) mtp_pick_shape(c->pot->alpha_index_basic_count, &kl_, &kb_);
+      c->dpad = kl_ * kb_;
+      c->d_dbasic.reserve((size_t) inum * c->dpad);
     }
   } catch (const HipFail &f) {
     c->last_error = f.what;
@@ -535,13 +556,14 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
   p.vflag = vflag;
   p.grade_flag = grade_flag ? 1 : 0;
   const bool team = !grade_flag && c->use_team;
-  const mtp_context::LaunchPlan &L = c->lp[grade_flag ? 1 : (team ? 2 : 0)];
+  const mtp_context::LaunchPlan &L = c->lp[team ? 2 : 0];
   p.tab_rows = L.tab_rows;
-  p.g_doubles = L.g_doubles;
   p.m_doubles = L.m_doubles;
   p.wave_doubles = L.wave_doubles;
   p.cvec = grade_flag ? c->d_cvec.ptr : nullptr;
   p.cpad = c->cpad;
+  p.dbasic = grade_flag ? c->d_dbasic.ptr : nullptr;
+  p.dpad = c->dpad;
   try {
     if (c->timing) {
       if (!c->ev0) {
@@ -558,6 +580,10 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
     }
     if ((eflag & MTP_ENERGY_GLOBAL) || vflag) HIP_CHECK(mtp_launch_ev_finish(c->d_ev_slots.ptr, d_ev, st));
     if (grade_flag) {
+      MtpDevParams pc = p;   // radial block of the candidate vectors from the adjoints left in HBM
+      pc.wave_doubles = c->lp[1].wave_doubles;
+      pc.tab_rows = c->lp[1].tab_rows;
+      HIP_CHECK(mtp_launch_cvec_kernel(pc, c->lp[1].grid, c->lp[1].wpb, c->lp[1].lds_bytes, st));
       if (cfg)
         HIP_CHECK(mtp_launch_colsum_kernel(c->d_cvec.ptr, c->cpad, c->pot->coeff_count, c->inum, d_coeff_ders, st));
       else

@@ -47,16 +47,17 @@ struct MtpDevParams {
   double *ev_slots;        // [MTP_EV_SLOTS][8]
   double *cvec;            // [inum][cpad] candidate vectors dE_i/dtheta (grade calls only)
   int cpad;                // row stride of cvec and of the padded inverse active set (multiple of 16)
+  double *dbasic;          // [inum][dpad] adjoints of the basics, zero padded (grade calls only)
+  int dpad;                // = KL*KB of the lane grid
   int *err_flag;
   unsigned long long *stamps;   // [16] diagnostic build only (MTP_STAMPS), else unused
   int eflag, vflag, grade_flag;
   // launch geometry
   int NT;                  // neighbours per LDS tile: 32 or 16 (table row pitch = NT + 2 doubles)
-  int tab_rows;            // table rows = 2*nslot + 3*P (+ P + R in grade calls: r^-nu and Q_ri rows)
+  int tab_rows;            // table rows = 2*nslot + 3*P 
   int cj_cap;              // capacity of the compacted id list
   int wave_doubles;        // LDS doubles per wavefront
   int m_doubles;           // doubles of the moment region = max(A, 4*KL*KB)
-  int g_doubles;           // grade calls: Mu*NT + Sp*Mu*R scratch doubles, else 0
   float inv_mu;            // 1 / Mu
 };
 
@@ -67,6 +68,8 @@ hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size
 int mtp_pick_team_shape(int B, int *KL, int *KBW);
 hipError_t mtp_launch_team_kernel(const MtpDevParams &p, int grid, size_t lds, hipStream_t st);
 hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st);
+// radial block of cvec from dbasic (grade calls, after the force kernel)
+hipError_t mtp_launch_cvec_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);
 // grades[ilist[ii]] = max_r |sum_c cvec[ii][c] Ainv[r][c]| (f64 MFMA), running maximum into max_grade
 hipError_t mtp_launch_grade_kernel(const double *cvec, const double *ainv_pad, int cpad, int C, int inum,
                                    const int *ilist, double *grades, double *max_grade, hipStream_t st);

@@ -39,7 +39,7 @@ namespace {
 
 template <int PITCH> struct WaveLds {
   static constexpr int NT = PITCH - 2;
-  double *M, *D, *tab, *nbx, *nby, *nbz, *nbr, *nbi, *red, *gw;
+  double *M, *D, *tab, *nbx, *nby, *nbz, *nbr, *nbi, *red;
   int *nbj, *nbjt, *cj;
   unsigned m_addr;   // LDS byte address of M
   __device__ __forceinline__ unsigned addr(const double *ptr) const { return m_addr + 8u * (unsigned) (ptr - M); }
@@ -55,8 +55,7 @@ template <int PITCH> struct WaveLds {
     nbr = nbz + NT;
     nbi = nbr + NT;
     red = nbi + NT;   // 64 doubles
-    gw = red + 64;    // grade calls only: W[mu][n] (Mu*NT) + staged radial block (Sp*Mu*R)
-    nbj = reinterpret_cast<int *>(gw + p.g_doubles);
+    nbj = reinterpret_cast<int *>(red + 64);
     nbjt = nbj + NT;
     cj = nbjt + NT;
   }
@@ -64,7 +63,7 @@ template <int PITCH> struct WaveLds {
 
 // Phase 2: tables of one tile; columns [0, ntp) are written, ntp = nt rounded up to the
 // neighbour-group count with dummy neighbours sitting exactly on the cutoff (g = dg = 0).
-template <int PITCH, bool GRADE>
+template <int PITCH>
 __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTables &bt, const WaveLds<PITCH> &w,
                                            int t0, int cnt, int ntp, bool gather, double xi0, double xi1,
                                            double xi2, int i, int itype, int lane)
@@ -103,19 +102,13 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
     double q0 = p.scaling * (d * d), q1 = p.scaling * (ksi * d * d);
     double e0 = p.scaling * 2.0 * d, e1 = p.scaling * (mult * d * d + 2.0 * ksi * d);
     double val = c[0] * q0, der = c[0] * e0;
-    // grade calls keep Q_ri(r_n) and r_n^-nu as extra rows (pair_mtp_extrapolation.cpp:193-198)
-    const bool extra = GRADE && mu == 0;
-    double *colq = w.tab + (size_t) (2 * p.nslot + 4 * P) * PITCH + n;
-    if (extra) colq[0] = q0;
     if (R > 1) {
       val += c[1] * q1;
       der += c[1] * e1;
-      if (extra) colq[PITCH] = q1;
     }
     for (int ri = 2; ri < R; ri++) {
       const double q2 = 2.0 * ksi * q1 - q0;
       const double e2 = 2.0 * (mult * q1 + ksi * e1) - e0;
-      if (extra) colq[ri * PITCH] = q2;
       val += c[ri] * q2;
       der += c[ri] * e2;
       q0 = q1;
@@ -133,7 +126,6 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
         col[s * PITCH] = g;                                       // f_mu / r^nu
         col[(p.nslot + s) * PITCH] = der * rp - nu * g * inv;     // d/dr (f_mu / r^nu)
       }
-      if (extra) col[(2 * p.nslot + 3 * P + nu) * PITCH] = rp;    // r^-nu
       rp *= inv;
     }
   }
@@ -344,7 +336,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     const int ntiles = (cnt + NT - 1) / NT;
     for (int tile = 0; tile < ntiles; tile++) {
       const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-      build_tile<PITCH, GRADE>(p, bt, w, t0, cnt, ntp, tile > 0, xi0, xi1, xi2, i, itype, lane);
+      build_tile<PITCH>(p, bt, w, t0, cnt, ntp, tile > 0, xi0, xi1, xi2, i, itype, lane);
       STAMP(2);   // tile tables
 #pragma unroll
       for (int m = 0; m < NPG; m++) {
@@ -415,6 +407,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
       const double d = ok ? w.D[k] : 0.0;
       const int pk = ok ? bt.pack[k] : 0;
       w.M[k] = d;
+      if (GRADE) p.dbasic[(size_t) ii * p.dpad + k] = d;   // read back by mtp_cvec_kernel
       w.M[KP + k] = d * (double) ((pk >> 8) & 15);
       w.M[2 * KP + k] = d * (double) ((pk >> 12) & 15);
       w.M[3 * KP + k] = d * (double) ((pk >> 16) & 15);
@@ -424,10 +417,9 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     wave_fence();
     // the 16 lanes with kl < BATCH collect: force on i (3), virial (6)
     double fi0 = 0, fi1 = 0, fi2 = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
-    double crad[4] = {0.0, 0.0, 0.0, 0.0};   // grade calls: this lane's entries of the radial block
     for (int tile = 0; tile < ntiles; tile++) {
       const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-      if (ntiles > 1) build_tile<PITCH, GRADE>(p, bt, w, t0, cnt, ntp, true, xi0, xi1, xi2, i, itype, lane);
+      if (ntiles > 1) build_tile<PITCH>(p, bt, w, t0, cnt, ntp, true, xi0, xi1, xi2, i, itype, lane);
 #pragma unroll
       for (int b = 0; b < NBATCH; b++) {
         if (b * BATCH * NG < ntp) {
@@ -502,72 +494,6 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
           }
           wave_fence();
         }
-      }
-      // ---- radial block of the candidate vector (pair_mtp_extrapolation.cpp:193-198, 323-329):
-      // c[jt][mu][ri] = sum_n [type_n = jt] Q_ri(r_n) W_mu(n),  W_mu(n) = sum_{k in mu} D_k mono_k(n) / r_n^nu_k
-      if (GRADE) {
-        const int row_r0 = 2 * ns + 3 * P, row_q0 = 2 * ns + 4 * P;
-        for (int mu0 = 0; mu0 < p.Mu; mu0 += 4) {
-#pragma unroll
-          for (int b = 0; b < NBATCH; b++) {
-            if (b * BATCH * NG < ntp) {
-              double wp[KL];
-#pragma unroll
-              for (int u = 0; u < KL; u++) wp[u] = 0.0;
-#pragma unroll
-              for (int t = 0; t < KB; t++) {
-                const int k = kl + KL * t;
-                const int pk = k < p.B ? bt.pack[k] : 0;
-                const int ml = ((pk >> 20) & 15) - mu0;
-                const int nu = ((pk >> 8) & 15) + ((pk >> 12) & 15) + ((pk >> 16) & 15);
-                const double Dk = lds_ld(pda, KL * t);
-                unsigned pr = w.addr(w.tab + (size_t) (row_r0 + nu) * PITCH + q);
-                asm volatile("" : "+v"(pr));
-#pragma unroll
-                for (int mm = 0; mm < BATCH; mm++) {
-                  const int o = (b * BATCH + mm) * NG;
-                  const double val = (Dk * lds_ld(pr, o)) *
-                      (lds_ld(px[t], PITCH + o) * (lds_ld(py[t], PITCH + o) * lds_ld(pz[t], PITCH + o)));
-#pragma unroll
-                  for (int u = 0; u < 4; u++) wp[4 * mm + u] += ml == u ? val : 0.0;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-              }
-              Butterfly<KL>::run(wp, lane);
-              const int mm = kl >> 2, mu = mu0 + (kl & 3);
-              const int n = q + NG * (b * BATCH + mm);
-              if (n < nt && mu < p.Mu) w.gw[mu * NT + n] = wp[0];
-            }
-          }
-        }
-        wave_fence();
-        const int MuR = p.Mu * p.R;
-#pragma unroll
-        for (int ce = 0; ce < 4; ce++) {
-          const int e = lane + 64 * ce;
-          if (e < p.Sp * MuR) {
-            const int jt = e / MuR, m = e - jt * MuR, mu = m / p.R, ri = m - mu * p.R;
-            const double *qrow = w.tab + (size_t) (row_q0 + ri) * PITCH;
-            double sum = 0.0;
-            for (int n = 0; n < nt; n++)
-              if (w.nbjt[n] == jt) sum += qrow[n] * w.gw[mu * NT + n];
-            crad[ce] += sum;
-          }
-        }
-        wave_fence();
-      }
-    }
-    if (GRADE) {   // stage the radial block, then write the whole radial part of the row
-      const int SMR = p.Sp * p.Mu * p.R;
-      double *stage = w.gw + p.Mu * NT;
-#pragma unroll
-      for (int ce = 0; ce < 4; ce++)
-        if (lane + 64 * ce < SMR) stage[lane + 64 * ce] = crad[ce];
-      wave_fence();
-      double *crow = p.cvec + (size_t) ii * p.cpad;
-      for (int e = lane; e < p.Sp * SMR; e += 64) {
-        const int blk = e / SMR;
-        crow[e] = blk == itype ? stage[e - blk * SMR] : 0.0;   // offset (itype*Sp + jt)*MuR + m
       }
     }
     STAMP(7);   // forces
