@@ -115,8 +115,9 @@ void mtp_context::plan()
     LaunchPlan &L = lp[0];
     L.tab_rows = 2 * p.slot_count + 3 * P;
     L.g_doubles = 0;
-    L.m_doubles = std::max(std::max(A, 4 * KL * KB), 144);
-    const size_t dbl = (size_t) A + L.m_doubles + (size_t) L.tab_rows * (nt + 2) + 5 * (size_t) nt + 64;
+    L.m_doubles = std::max(std::max(A, 3 * KL * KB), 144);
+    const int d_doubles = std::max(A, p.alpha_index_basic_count + 64);
+    const size_t dbl = (size_t) d_doubles + L.m_doubles + (size_t) L.tab_rows * (nt + 2) + 5 * (size_t) nt;
     const size_t ints = (size_t) 2 * nt + cap;
     const size_t wb = (dbl * 8 + ints * 4 + 15) / 16 * 16;
     // waves per CU for w waves per workgroup; registers allow 8 (2 per SIMD)
@@ -174,7 +175,7 @@ void mtp_context::plan()
     L.tab_rows = 2 * p.slot_count + 3 * P;
     L.g_doubles = 0;
     L.m_doubles = std::max(std::max(A, 4 * TKL * TKBW * 4), 144);
-    const size_t dbl = (size_t) A + L.m_doubles + (size_t) L.tab_rows * (nt + 2) + 5 * (size_t) nt + 4 * 64;
+    const size_t dbl = (size_t) std::max(A, p.alpha_index_basic_count + 64) + L.m_doubles + (size_t) L.tab_rows * (nt + 2) + 5 * (size_t) nt + 4 * 64;
     const size_t ints = (size_t) 2 * nt + 8 + cap;
     const size_t wb = (dbl * 8 + ints * 4 + 15) / 16 * 16;
     const size_t blk = blob + wb;
@@ -195,6 +196,7 @@ void mtp_context::plan()
   }
   base.NT = nt;
   base.cj_cap = cap;
+  base.d_doubles = std::max(A, p.alpha_index_basic_count + 64);
 }
 
 extern "C" {
@@ -325,7 +327,12 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     c->d_rows.upload(rows8.data(), rows8.size(), st);
     // table blob copied into LDS by every workgroup
     MtpDevParams &bb = c->base;
-    bb.rows_in_lds = rows8.size() * sizeof(MtpRow8) <= 24 * 1024;
+    // The packed rows stay in HBM/L2 unless they are tiny: measured cost at level 16 is < 1 % (row
+    // reads do not depend on data), and without them in every workgroup's LDS one more wavefront fits per CU.
+    bb.rows_in_lds = rows8.size() * sizeof(MtpRow8) <= 1024;
+    if (const char *e = std::getenv("MTP_ROWS_LDS")) {   // tuning override (benchmarks only)
+      if (std::atoi(e) != 0 && rows8.size() * sizeof(MtpRow8) <= 24 * 1024) bb.rows_in_lds = 1;
+    }
     std::vector<unsigned char> blob;
     auto put = [&](const void *src, size_t bytes) {
       size_t off = (blob.size() + 7) / 8 * 8;

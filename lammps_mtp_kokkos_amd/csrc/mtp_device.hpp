@@ -57,7 +57,8 @@ struct MtpDevParams {
   int tab_rows;            // table rows = 2*nslot + 3*P 
   int cj_cap;              // capacity of the compacted id list
   int wave_doubles;        // LDS doubles per wavefront
-  int m_doubles;           // doubles of the moment region = max(A, 4*KL*KB)
+  int m_doubles;           // doubles of the moment region = max(A, 3*KL*KB, 144)
+  int d_doubles;           // doubles of the adjoint region = max(A, B + 64)
   float inv_mu;            // 1 / Mu
 };
 

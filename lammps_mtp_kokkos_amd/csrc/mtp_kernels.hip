@@ -48,14 +48,14 @@ template <int PITCH> struct WaveLds {
     M = base;
     m_addr = base_addr;
     D = M + p.m_doubles;   // M region also hosts the exponent-weighted adjoints in phase 5
-    tab = D + p.A;
+    tab = D + p.d_doubles;   // adjoint region: max(A, B + 64) doubles
     nbx = tab + (size_t) p.tab_rows * PITCH;
     nby = nbx + NT;
     nbz = nby + NT;
     nbr = nbz + NT;
     nbi = nbr + NT;
-    red = nbi + NT;   // 64 doubles
-    nbj = reinterpret_cast<int *>(red + 64);
+    red = D + p.B;    // 64 doubles in the tail of the adjoint region: only D[0,B) is live in the force phase
+    nbj = reinterpret_cast<int *>(nbi + NT);
     nbjt = nbj + NT;
     cj = nbjt + NT;
   }
@@ -399,19 +399,21 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
 
     STAMP(6);   // products backward
     // ---- 5. forces ---------------------------------------------------------------------------
-    // adjoints of the basics, plain and times the chain-rule exponents, go into the (now
-    // free) moment region, zero-padded to KL*KB: DK/DA/DB/DC, read back with immediate offsets
+    // adjoints of the basics times the chain-rule exponents go into the (now free) moment region,
+    // zero-padded to KL*KB: DA/DB/DC, read back with immediate offsets; D_k itself is read from the
+    // adjoint region (lanes past B are masked)
     constexpr int KP = KL * KB;
     for (int k = lane; k < KP; k += 64) {
       const bool ok = k < p.B;
       const double d = ok ? w.D[k] : 0.0;
       const int pk = ok ? bt.pack[k] : 0;
-      w.M[k] = d;
       if (GRADE) p.dbasic[(size_t) ii * p.dpad + k] = d;   // read back by mtp_cvec_kernel
-      w.M[KP + k] = d * (double) ((pk >> 8) & 15);
-      w.M[2 * KP + k] = d * (double) ((pk >> 12) & 15);
-      w.M[3 * KP + k] = d * (double) ((pk >> 16) & 15);
+      w.M[k] = d * (double) ((pk >> 8) & 15);
+      w.M[KP + k] = d * (double) ((pk >> 12) & 15);
+      w.M[2 * KP + k] = d * (double) ((pk >> 16) & 15);
     }
+    unsigned pdd = w.addr(w.D + kl);
+    asm volatile("" : "+v"(pdd));
     unsigned pda = w.addr(w.M + kl);
     asm volatile("" : "+v"(pda));
     wave_fence();
@@ -429,8 +431,9 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
           // stale columns beyond ntp only feed their own (discarded) slots of `part`
 #pragma unroll
           for (int t = 0; t < KB; t++) {
-            const double Dk = lds_ld(pda, KL * t), Da = lds_ld(pda, KP + KL * t);
-            const double Db = lds_ld(pda, 2 * KP + KL * t), Dc = lds_ld(pda, 3 * KP + KL * t);
+            const double Dk_raw = lds_ld(pdd, KL * t), Da = lds_ld(pda, KL * t);   // unconditional (volatile) read
+            const double Dk = kval[t] ? Dk_raw : 0.0;
+            const double Db = lds_ld(pda, KP + KL * t), Dc = lds_ld(pda, 2 * KP + KL * t);
             constexpr int MC = BATCH < 4 ? BATCH : 4;   // columns per burst (8 reads each)
 #pragma unroll
             for (int m0 = 0; m0 < BATCH; m0 += MC) {

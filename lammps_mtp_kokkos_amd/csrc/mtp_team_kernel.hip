@@ -33,7 +33,7 @@ template <int PITCH, int WPA> struct TeamLds {
     M = base;
     m_addr = base_addr;
     D = M + p.m_doubles;
-    tab = D + p.A;
+    tab = D + p.d_doubles;
     nbx = tab + (size_t) p.tab_rows * PITCH;
     nby = nbx + NT;
     nbz = nby + NT;
