@@ -371,6 +371,60 @@ int mtp_potential::finalize(std::string &err)
     }
   }
   // level l (1-based) spans [level_offset[l-1], level_offset[l])
+  // Rows of one level commute, so order them for the LDS: a wave instruction touches 64 consecutive
+  // rows, served in lane groups of 32 (reads) / 16 (ds_add_f64).  Greedy: fill each group of 16 with
+  // the rows whose operand and target moments fall on banks not yet used by a different moment of the
+  // group (same moment = broadcast for reads, but serialised for the atomic adds).
+  for (int l = 1; l <= nlev; l++) {
+    const int b = level_offset[l - 1], e = level_offset[l];
+    const int n = e - b;
+    if (n <= 16) continue;
+    std::vector<MtpRow> pool(rows_by_level.begin() + b, rows_by_level.begin() + e), out;
+    std::vector<char> used((size_t) n, 0);
+    out.reserve((size_t) n);
+    int remaining = n, scan_from = 0;
+    while (remaining > 0) {
+      int rd0[32], rd1[32], rd3[32];          // moment occupying each read bank in the current 32-group (-1 free)
+      for (int h = 0; h < 2 && remaining > 0; h++) {   // two 16-lane halves share the 32-lane read group
+        if (h == 0)
+          for (int q = 0; q < 32; q++) rd0[q] = rd1[q] = rd3[q] = -1;
+        int at0[16], at1[16], at3[16];        // atomic-add banks of this 16-group
+        for (int q = 0; q < 16; q++) at0[q] = at1[q] = at3[q] = -1;
+        for (int slot = 0; slot < 16 && remaining > 0; slot++) {
+          int best = -1, best_cost = 1 << 30;
+          int seen = 0;
+          for (int k = scan_from; k < n && seen < 256; k++) {   // bounded look-ahead keeps this O(n * 256)
+            if (used[k]) continue;
+            seen++;
+            const MtpRow &r = pool[k];
+            int cost = 0;
+            cost += (rd0[r.a0 & 31] >= 0 && rd0[r.a0 & 31] != r.a0);
+            cost += (rd1[r.a1 & 31] >= 0 && rd1[r.a1 & 31] != r.a1);
+            cost += (rd3[r.a3 & 31] >= 0 && rd3[r.a3 & 31] != r.a3);
+            cost += 2 * (at3[r.a3 & 15] >= 0);            // forward ds_add target
+            cost += (at0[r.a0 & 15] >= 0) + (at1[r.a1 & 15] >= 0);   // backward ds_add targets
+            if (cost < best_cost) {
+              best_cost = cost;
+              best = k;
+              if (cost == 0) break;
+            }
+          }
+          const MtpRow &r = pool[best];
+          used[best] = 1;
+          remaining--;
+          while (scan_from < n && used[scan_from]) scan_from++;
+          rd0[r.a0 & 31] = r.a0;
+          rd1[r.a1 & 31] = r.a1;
+          rd3[r.a3 & 31] = r.a3;
+          at0[r.a0 & 15] = r.a0;
+          at1[r.a1 & 15] = r.a1;
+          at3[r.a3 & 15] = r.a3;
+          out.push_back(r);
+        }
+      }
+    }
+    std::copy(out.begin(), out.end(), rows_by_level.begin() + b);
+  }
   for (int i = 0; i < S; i++)
     if (alpha_moment_mapping[i] < 0 || alpha_moment_mapping[i] >= A) {
       err = "alpha_moment_mapping refers to a moment outside alpha_moments_count";
