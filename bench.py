@@ -122,8 +122,29 @@ def main():
     grades_t = torch.zeros(plan.nall, dtype=torch.float64, device=dev) if grade else None
     maxg_t = torch.zeros(1, dtype=torch.float64, device=dev) if grade else None
 
+    # N > 1: atoms whose list holds no ghost are computed while the forward halo is in flight
+    overlap = world > 1 and not grade and os.environ.get("MTP_BENCH_OVERLAP", "1") != "0"
+    if overlap:
+        from lammps_mtp_kokkos_amd.domain import split_interior, sub_list
+        rows_int, rows_bnd = split_interior(plan)
+        parts = []
+        for rows in (rows_int, rows_bnd):
+            c2 = capi.Context(pot, devidx)
+            c2.set_variant(dict(auto=0, large=1, small=2)[args.variant])
+            il2, fi2, ne2 = (torch.from_numpy(a).to(dev) for a in sub_list(plan, rows))
+            c2.set_neighbors_device(il2, fi2, ne2, plan.nall, max_nn)
+            parts.append(c2)
+        ctx_int, ctx_bnd = parts
+
     def step():
         f.zero_()
+        if overlap:
+            h = halo.forward_begin(x)
+            ctx_int.compute_device(x, ty, f, eflag=EFLAG, vflag=VFLAG, ev_t=ev, stream=stream)
+            halo.forward_end(h)
+            ctx_bnd.compute_device(x, ty, f, eflag=EFLAG, vflag=VFLAG, ev_t=ev, stream=stream)
+            halo.reverse(f)
+            return
         if world > 1:
             halo.forward(x)
         ctx.compute_device(x, ty, f, eflag=EFLAG, vflag=VFLAG, ev_t=ev, stream=stream, grade=grade,
@@ -226,7 +247,8 @@ def main():
                                       sizes["B"], sizes["T"], sizes["S"], sizes["A"], sizes["R"], sizes["Mu"], sizes["C"],
                                       ", neighbourhood grades every step" if grade else ""),
                        "atoms": natoms, "potential": os.path.basename(args.potential),
-                       "parallelism": "domain decomposition %s, RCCL all-to-all halo" % "x".join(map(str, plan.grid))
+                       "parallelism": ("domain decomposition %s, RCCL all-to-all halo%s" % (
+                           "x".join(map(str, plan.grid)), ", interior atoms overlap the forward halo" if overlap else ""))
                        if world > 1 else "single GPU",
                        "atoms_rank0": plan.nlocal, "ghosts_rank0": plan.nghost, "list_entries_rank0": int(plan.first[-1]),
                        "in_cutoff_pairs_rank0": jc_total, "launch": info},

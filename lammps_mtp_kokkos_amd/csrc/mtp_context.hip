@@ -497,6 +497,12 @@ int mtp_set_neighbors(mtp_context *c, int inum, const int *ilist, const int *num
 {
   if (!c || inum < 0 || (inum > 0 && (!ilist || !numneigh || !firstneigh))) return MTP_ERR_ARG;
   std::vector<int> first((size_t) inum + 1, 0);
+  long long total = 0;
+  for (int ii = 0; ii < inum; ii++) total += numneigh[ilist[ii]];
+  if (total > 2147483647LL) {
+    c->last_error = "neighbour list has more than 2^31-1 entries on this rank";
+    return MTP_ERR_LIMIT;
+  }
   for (int ii = 0; ii < inum; ii++) first[ii + 1] = first[ii] + numneigh[ilist[ii]];
   std::vector<int> neigh((size_t) first[inum]);
   for (int ii = 0; ii < inum; ii++) {
@@ -510,6 +516,7 @@ int mtp_set_neighbors_device(mtp_context *c, int inum, const int *d_ilist, const
                              const int *d_neigh, int nall, int max_numneigh)
 {
   if (!c || inum < 0 || nall < inum || max_numneigh < 0 || (inum > 0 && (!d_ilist || !d_first))) return MTP_ERR_ARG;
+  (void) hipSetDevice(c->device);
   c->ilist = d_ilist;
   c->first = d_first;
   c->neigh = d_neigh;
@@ -547,6 +554,10 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
   }
   if (((eflag & MTP_ENERGY_GLOBAL) || vflag) && !d_ev) return MTP_ERR_ARG;
   if (c->inum == 0) return MTP_OK;
+  if (hipSetDevice(c->device) != hipSuccess) {
+    c->last_error = "hipSetDevice failed";
+    return MTP_ERR_DEVICE;
+  }
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
   MtpDevParams p = c->base;
   p.inum = c->inum;

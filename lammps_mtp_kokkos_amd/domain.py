@@ -170,8 +170,55 @@ class HaloExchange:
         self.sendbuf += self.send_shift
         self._a2a(x[p.nlocal:], self.sendbuf, p.recv_counts, p.send_counts)
 
+    def forward_begin(self, x):
+        """Start the forward halo and return a handle for forward_end(); force work that needs no
+        ghost positions (interior atoms) can be queued in between and overlaps the exchange."""
+        import torch.distributed as dist
+        p = self.plan
+        self.torch.index_select(x[: p.nlocal], 0, self.send_idx, out=self.sendbuf)
+        self.sendbuf += self.send_shift
+        if self.single or (self.sendbuf.is_cuda and dist.get_backend(self.group) == "gloo"):
+            self._a2a(x[p.nlocal:], self.sendbuf, p.recv_counts, p.send_counts)
+            return None
+        return dist.all_to_all_single(x[p.nlocal:], self.sendbuf, output_split_sizes=p.recv_counts,
+                                      input_split_sizes=p.send_counts, group=self.group, async_op=True)
+
+    @staticmethod
+    def forward_end(handle):
+        if handle is not None:
+            handle.wait()      # the current stream now waits for the exchange
+
     def reverse(self, f):
         """f [nall,3]: add the ghost rows' forces into their owners (on the owning ranks)."""
         p = self.plan
         self._a2a(self.frecv, f[p.nlocal:], p.send_counts, p.recv_counts)
         f[: p.nlocal].index_add_(0, self.send_idx, self.frecv)
+
+
+def split_interior(plan: HaloPlan):
+    """Indices (into plan.ilist) of owned atoms whose list holds no ghost (interior: computable
+    before the forward halo lands) and of those that do (boundary)."""
+    has_ghost = np.zeros(plan.nlocal, dtype=bool)
+    if plan.nlocal:
+        ghost_entry = plan.neigh >= plan.nlocal
+        counts = np.diff(plan.first)
+        row = np.repeat(np.arange(plan.nlocal), counts)
+        np.logical_or.at(has_ghost, row, ghost_entry)
+    interior = np.nonzero(~has_ghost)[0]
+    boundary = np.nonzero(has_ghost)[0]
+    return interior, boundary
+
+
+def sub_list(plan: HaloPlan, rows):
+    """CSR neighbour list restricted to the given owned atoms."""
+    rows = np.asarray(rows, dtype=np.int64)
+    counts = (plan.first[rows + 1] - plan.first[rows]).astype(np.int64)
+    first = np.zeros(len(rows) + 1, dtype=np.int32)
+    np.cumsum(counts, out=first[1:])
+    if len(rows):
+        idx = np.concatenate([np.arange(plan.first[r], plan.first[r + 1]) for r in rows]) if len(rows) < 4096 else \
+            (np.repeat(plan.first[rows].astype(np.int64) - first[:-1], counts) + np.arange(first[-1]))
+        neigh = plan.neigh[idx]
+    else:
+        neigh = np.zeros(0, dtype=np.int32)
+    return plan.ilist[rows].astype(np.int32), first, neigh.astype(np.int32)

@@ -29,24 +29,43 @@ def main():
     potf = os.path.join(ROOT, "potentials", "WRe_L20.mtp")
     pot = capi.Potential(potf)
 
-    def forces(plan):
-        ctx = capi.Context(pot, dev.index)
-        il, fi, ne = (torch.from_numpy(a).to(dev) for a in (plan.ilist, plan.first, plan.neigh))
-        ctx.set_neighbors_device(il, fi, ne, plan.nall, int(np.diff(plan.first).max()))
+    def forces(plan, split=False):
+        """split: interior atoms are computed between forward_begin/forward_end (bench.py's overlap path)"""
+        from lammps_mtp_kokkos_amd.domain import split_interior, sub_list
+        st = torch.cuda.current_stream().cuda_stream
+        max_nn = int(np.diff(plan.first).max())
         x = torch.from_numpy(plan.x0).to(dev)
         x[plan.nlocal:] = 0.0
         halo = HaloExchange(plan, dev)
-        halo.forward(x)
         ty = torch.from_numpy(plan.types).to(dev)
         f = torch.zeros((plan.nall, 3), dtype=torch.float64, device=dev)
         ev = torch.zeros(8, dtype=torch.float64, device=dev)
-        ctx.compute_device(x, ty, f, eflag=1, vflag=1, ev_t=ev, stream=torch.cuda.current_stream().cuda_stream)
-        ctx.synchronize(torch.cuda.current_stream().cuda_stream)
+        keep = []
+        if split:
+            ctxs = []
+            for rows in split_interior(plan):
+                c = capi.Context(pot, dev.index)
+                t3 = [torch.from_numpy(a).to(dev) for a in sub_list(plan, rows)]
+                c.set_neighbors_device(*t3, plan.nall, max_nn)
+                ctxs.append(c)
+                keep.append(t3)
+            h = halo.forward_begin(x)
+            ctxs[0].compute_device(x, ty, f, eflag=1, vflag=1, ev_t=ev, stream=st)
+            halo.forward_end(h)
+            ctxs[1].compute_device(x, ty, f, eflag=1, vflag=1, ev_t=ev, stream=st)
+            ctxs[1].synchronize(st)
+        else:
+            ctx = capi.Context(pot, dev.index)
+            il, fi, ne = (torch.from_numpy(a).to(dev) for a in (plan.ilist, plan.first, plan.neigh))
+            ctx.set_neighbors_device(il, fi, ne, plan.nall, max_nn)
+            halo.forward(x)
+            ctx.compute_device(x, ty, f, eflag=1, vflag=1, ev_t=ev, stream=st)
+            ctx.synchronize(st)
         halo.reverse(f)
         return f[: plan.nlocal].cpu().numpy(), ev
 
     plan = decompose(pos, box, types, world, rank, 7.0)
-    f, ev = forces(plan)
+    f, ev = forces(plan, split=os.environ.get("MTP_CHECK_SPLIT", "1") != "0")
     dist.all_reduce(ev)
     parts = [None] * world
     dist.all_gather_object(parts, (plan.owned_global, f))
