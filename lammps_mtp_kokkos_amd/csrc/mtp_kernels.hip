@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
             const double Dk_raw = lds_ld(pdd, KL * t), Da = lds_ld(pda, KL * t);   // unconditional (volatile) read
             const double Dk = kval[t] ? Dk_raw : 0.0;
             const double Db = lds_ld(pda, KP + KL * t), Dc = lds_ld(pda, 2 * KP + KL * t);
-            constexpr int MC = BATCH < 4 ? BATCH : 4;   // columns per burst (8 reads each)
+            constexpr int MC = KL >= 32 ? 2 : (BATCH < 4 ? BATCH : 4);   // columns per burst (8 reads each); wide grids keep bursts short (registers)
 #pragma unroll
             for (int m0 = 0; m0 < BATCH; m0 += MC) {
               double g[MC], gd[MC], xm[MC], xa[MC], ym[MC], yb[MC], zm[MC], zc[MC];
