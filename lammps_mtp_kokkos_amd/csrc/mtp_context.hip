@@ -335,14 +335,18 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     }
     std::vector<unsigned char> blob;
     auto put = [&](const void *src, size_t bytes) {
-      size_t off = (blob.size() + 7) / 8 * 8;
+      size_t off = (blob.size() + 15) / 16 * 16;
       blob.resize(off + bytes, 0);
       if (bytes) std::memcpy(blob.data() + off, src, bytes);
       return (int) off;
     };
     bb.off_rows = bb.rows_in_lds ? put(rows8.data(), rows8.size() * sizeof(MtpRow8)) : 0;
     bb.off_level = put(pot->level_offset.data(), pot->level_offset.size() * sizeof(int32_t));
-    bb.off_slot = put(pot->slot_of.data(), pot->slot_of.size() * sizeof(int32_t));
+    std::vector<int32_t> slot_pad((size_t) pot->radial_func_count * MTP_PSTRIDE, -1);
+    for (int mu = 0; mu < pot->radial_func_count; mu++)
+      for (int nu = 0; nu < pot->max_alpha_index_basic; nu++)
+        slot_pad[(size_t) mu * MTP_PSTRIDE + nu] = pot->slot_of[(size_t) mu * pot->max_alpha_index_basic + nu];
+    bb.off_slot = put(slot_pad.data(), slot_pad.size() * sizeof(int32_t));
     bb.off_radial = put(pot->radial_basis_coeffs.data(), pot->radial_basis_coeffs.size() * sizeof(double));
     bb.off_seed_idx = put(pot->seed_idx.data(), pot->seed_idx.size() * sizeof(int32_t));
     bb.off_seed_val = put(pot->seed_val.data(), pot->seed_val.size() * sizeof(double));
@@ -388,6 +392,7 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     b.rmax = pot->max_cutoff;
     b.scaling = pot->scaling;
     b.cutsq = pot->max_cutoff * pot->max_cutoff;   // pair_mtp.cpp:449,456
+    b.inv_span = 1.0 / (pot->max_cutoff - pot->min_cutoff);
     b.blob = c->d_blob.ptr;
     b.rows = c->d_rows.ptr;
     b.species_coeffs = c->d_species.ptr;

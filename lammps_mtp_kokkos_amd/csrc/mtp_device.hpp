@@ -8,6 +8,7 @@
 
 #define MTP_EV_SLOTS 1024   // per-wave energy/virial tally slots (8 doubles each)
 #define MTP_MAX_WPB 8       // wavefronts per workgroup (512 threads)
+#define MTP_PSTRIDE 12      // slot ids per mu in the LDS blob (nu = 0..11, -1 padded)
 
 // A times row packed in 8 bytes: lo = a0 | a1 << 16, hi = a3 | (mult & 0xffff) << 16
 struct MtpRow8 {
@@ -18,14 +19,14 @@ struct MtpDevParams {
   // potential sizes
   int Sp, R, Mu, P, A, B, T, S, C;
   int nslot, nlevels, nseed;
-  double rmin, rmax, scaling, cutsq;
+  double rmin, rmax, scaling, cutsq, inv_span;   // inv_span = 1 / (rmax - rmin)
   // Read-mostly tables, one contiguous blob in HBM that every workgroup copies into the
   // head of its LDS once; offsets in bytes from the blob start (all 8-byte aligned).
   const unsigned char *blob;
   int blob_bytes;          // multiple of 16
   int off_rows;            // MtpRow8[T]   (only when rows_in_lds)
   int off_level;           // int[nlevels+1]
-  int off_slot;            // int[Mu*P]
+  int off_slot;            // int[Mu][MTP_PSTRIDE], -1 padded, 16-byte aligned
   int off_radial;          // double[Sp*Sp*Mu*R]
   int off_seed_idx;        // int[nseed]
   int off_seed_val;        // double[nseed]

@@ -90,43 +90,71 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
     wave_fence();
   }
   const int Mu = p.Mu, P = p.P, R = p.R;
-  const double span = p.rmax - p.rmin, mult = 2.0 / span;
+  const double mult = 2.0 * p.inv_span;
   for (int idx = lane; idx < ntp * Mu; idx += 64) {
     const int n = __float2int_rz((idx + 0.5f) * p.inv_mu), mu = idx - n * Mu;
     const double r = w.nbr[n], inv = w.nbi[n];
     const int jt = w.nbjt[n];
+    // slot ids of this mu for nu = 0..11 (padded with -1 on the host): three 16-byte LDS reads,
+    // issued before the recurrence so their latency hides under it
+    const int4 *sl4 = reinterpret_cast<const int4 *>(bt.slot + mu * MTP_PSTRIDE);
+    const int4 sa = sl4[0], sb = sl4[1], sc = sl4[2];
+    const int sv[MTP_PSTRIDE] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w, sc.x, sc.y, sc.z, sc.w};
     const double *c = bt.radial + ((itype * p.Sp + jt) * Mu + mu) * R;
     // Chebyshev values/derivatives by recurrence, contracted on the fly
     const double d = r - p.rmax;
-    const double ksi = (2.0 * r - (p.rmin + p.rmax)) / span;
+    const double ksi = (2.0 * r - (p.rmin + p.rmax)) * p.inv_span;
     double q0 = p.scaling * (d * d), q1 = p.scaling * (ksi * d * d);
     double e0 = p.scaling * 2.0 * d, e1 = p.scaling * (mult * d * d + 2.0 * ksi * d);
-    double val = c[0] * q0, der = c[0] * e0;
-    if (R > 1) {
-      val += c[1] * q1;
-      der += c[1] * e1;
-    }
-    for (int ri = 2; ri < R; ri++) {
-      const double q2 = 2.0 * ksi * q1 - q0;
-      const double e2 = 2.0 * (mult * q1 + ksi * e1) - e0;
-      val += c[ri] * q2;
-      der += c[ri] * e2;
-      q0 = q1;
-      q1 = q2;
-      e0 = e1;
-      e1 = e2;
+    double val, der;
+    if (R == 8) {   // the MLIP default: all eight coefficients in one burst of 16-byte reads, straight-line recurrence
+      const double2 *c2 = reinterpret_cast<const double2 *>(c);
+      const double2 c01 = c2[0], c23 = c2[1], c45 = c2[2], c67 = c2[3];
+      const double cc[8] = {c01.x, c01.y, c23.x, c23.y, c45.x, c45.y, c67.x, c67.y};
+      val = cc[0] * q0 + cc[1] * q1;
+      der = cc[0] * e0 + cc[1] * e1;
+#pragma unroll
+      for (int ri = 2; ri < 8; ri++) {
+        const double q2 = 2.0 * ksi * q1 - q0;
+        const double e2 = 2.0 * (mult * q1 + ksi * e1) - e0;
+        val += cc[ri] * q2;
+        der += cc[ri] * e2;
+        q0 = q1;
+        q1 = q2;
+        e0 = e1;
+        e1 = e2;
+      }
+    } else {
+      val = c[0] * q0;
+      der = c[0] * e0;
+      if (R > 1) {
+        val += c[1] * q1;
+        der += c[1] * e1;
+      }
+      for (int ri = 2; ri < R; ri++) {
+        const double q2 = 2.0 * ksi * q1 - q0;
+        const double e2 = 2.0 * (mult * q1 + ksi * e1) - e0;
+        val += c[ri] * q2;
+        der += c[ri] * e2;
+        q0 = q1;
+        q1 = q2;
+        e0 = e1;
+        e1 = e2;
+      }
     }
     double *col = w.tab + n;
-    const int *sl = bt.slot + mu * P;
     double rp = 1.0;
-    for (int nu = 0; nu < P; nu++) {
-      const int s = sl[nu];
-      const double g = val * rp;
-      if (s >= 0) {
-        col[s * PITCH] = g;                                       // f_mu / r^nu
-        col[(p.nslot + s) * PITCH] = der * rp - nu * g * inv;     // d/dr (f_mu / r^nu)
+#pragma unroll
+    for (int nu = 0; nu < MTP_PSTRIDE; nu++) {
+      if (nu < P) {
+        const int sidx = sv[nu];
+        const double g = val * rp;
+        if (sidx >= 0) {
+          col[sidx * PITCH] = g;                                       // f_mu / r^nu
+          col[(p.nslot + sidx) * PITCH] = der * rp - nu * g * inv;     // d/dr (f_mu / r^nu)
+        }
+        rp *= inv;
       }
-      rp *= inv;
     }
   }
   for (int idx = lane; idx < ntp * 3; idx += 64) {

@@ -338,6 +338,10 @@ int mtp_potential::finalize(std::string &err)
       return MTP_ERR_LIMIT;
     }
   }
+  if (max_alpha_index_basic > 12) {
+    err = "tensor rank above 11 is not supported by this build";
+    return MTP_ERR_LIMIT;
+  }
   std::vector<int> wlevel((size_t) A, 0), rlevel((size_t) A, 0);
   std::vector<int> lvl((size_t) T, 0);
   int nlev = 0;

@@ -102,7 +102,7 @@ __device__ __forceinline__ void team_build_tile(const MtpDevParams &p, const Blo
       e1 = e2;
     }
     double *col = w.tab + n;
-    const int *sl = bt.slot + mu * P;
+    const int *sl = bt.slot + mu * MTP_PSTRIDE;
     double rp = 1.0;
     for (int nu = 0; nu < P; nu++) {
       const int s = sl[nu];
