@@ -84,8 +84,7 @@ struct mtp_context {
   struct LaunchPlan {
     int wpb = 1, grid = 1, wave_doubles = 0, tab_rows = 0, g_doubles = 0, m_doubles = 0;
     size_t lds_bytes = 0;
-  } lp[3];   // [0] force calls (wavefront per atom), [1] grade calls, [2] force calls (workgroup per atom)
-  bool use_team = false;
+  } lp[2];   // [0] force calls (wavefront per atom), [1] candidate-vector kernel of grade calls
   DevBuf<double> d_cvec, d_ainv_pad, d_dbasic;
   int cpad = 0, dpad = 0;
   // timing
@@ -115,8 +114,8 @@ void mtp_context::plan()
     LaunchPlan &L = lp[0];
     L.tab_rows = 2 * p.slot_count + 3 * P;
     L.g_doubles = 0;
-    L.m_doubles = std::max(std::max(A, 3 * KL * KB), 144);
-    const int d_doubles = std::max(A, p.alpha_index_basic_count + 64);
+    L.m_doubles = std::max(std::max(A, p.coef_total), 16);   // moments, later the derivative-polynomial coefficients
+    const int d_doubles = A;
     const size_t dbl = (size_t) d_doubles + L.m_doubles + (size_t) L.tab_rows * (nt + 2) + 5 * (size_t) nt;
     const size_t ints = (size_t) 2 * nt + cap;
     const size_t wb = (dbl * 8 + ints * 4 + 15) / 16 * 16;
@@ -168,35 +167,9 @@ void mtp_context::plan()
     L.m_doubles = KL * KB;
     L.g_doubles = 0;
   }
-  {   // workgroup-per-atom plan: 4 wavefronts share one atom's LDS image; 128 VGPRs -> up to 4 workgroups per CU
-    LaunchPlan &L = lp[2];
-    int TKL = 16, TKBW = 1;
-    const bool ok = mtp_pick_team_shape(p.alpha_index_basic_count, &TKL, &TKBW) == 0;
-    L.tab_rows = 2 * p.slot_count + 3 * P;
-    L.g_doubles = 0;
-    L.m_doubles = std::max(std::max(A, 4 * TKL * TKBW * 4), 144);
-    const size_t dbl = (size_t) std::max(A, p.alpha_index_basic_count + 64) + L.m_doubles + (size_t) L.tab_rows * (nt + 2) + 5 * (size_t) nt + 4 * 64;
-    const size_t ints = (size_t) 2 * nt + 8 + cap;
-    const size_t wb = (dbl * 8 + ints * 4 + 15) / 16 * 16;
-    const size_t blk = blob + wb;
-    int per_cu = ok && blk <= LDS ? std::min<int>(4, (int) (LDS / blk)) : 0;
-    if (const char *e = std::getenv("MTP_TEAM_PER_CU")) {   // tuning override (benchmarks only)
-      int v = std::atoi(e);
-      if (v >= 1 && v <= 8 && (size_t) v * blk <= LDS) per_cu = v;
-    }
-    L.wpb = 4;
-    L.wave_doubles = (int) (wb / 8);
-    L.lds_bytes = blk;
-    L.grid = per_cu > 0 ? std::max(1, std::min(inum, num_cus * per_cu)) : 0;
-    // Experimental: measured SLOWER than the wavefront-per-atom kernel at every size tried on MI355X
-    // (65,536 atoms: 1.63 vs 1.08 ms; 1,024 atoms: 51 vs 32 us) -- the per-atom chain of dependent LDS
-    // round trips does not shrink with more wavefronts, and barriers are added.  Only MTP_TEAM=1 selects it.
-    use_team = false;
-    if (const char *e = std::getenv("MTP_TEAM")) use_team = L.grid > 0 && std::atoi(e) != 0;
-  }
   base.NT = nt;
   base.cj_cap = cap;
-  base.d_doubles = std::max(A, p.alpha_index_basic_count + 64);
+  base.d_doubles = A;
 }
 
 extern "C" {
@@ -353,6 +326,7 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     bb.off_map = put(pot->alpha_moment_mapping.data(), pot->alpha_moment_mapping.size() * sizeof(int32_t));
     bb.off_lin = put(pot->linear_coeffs.data(), pot->linear_coeffs.size() * sizeof(double));
     bb.off_pack = put(pot->basic_pack.data(), pot->basic_pack.size() * sizeof(int32_t));
+    bb.off_coef = put(pot->slot_coef_off.data(), pot->slot_coef_off.size() * sizeof(int32_t));
     blob.resize((blob.size() + 15) / 16 * 16, 0);
     bb.blob_bytes = (int) blob.size();
     c->d_blob.upload(blob.data(), blob.size(), st);
@@ -386,6 +360,11 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     b.S = pot->alpha_scalar_count;
     b.C = pot->coeff_count;
     b.nslot = pot->slot_count;
+    b.coef_total = pot->coef_total;
+    for (int d = 0; d <= MTP_PSTRIDE; d++) {
+      b.deg_first[d] = pot->deg_first[d];
+      b.deg_coef[d] = pot->deg_coef[d];
+    }
     b.nlevels = (int) pot->level_offset.size() - 1;
     b.nseed = (int) pot->seed_idx.size();
     b.rmin = pot->min_cutoff;
@@ -578,8 +557,7 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
   p.eflag = eflag;
   p.vflag = vflag;
   p.grade_flag = grade_flag ? 1 : 0;
-  const bool team = !grade_flag && c->use_team;
-  const mtp_context::LaunchPlan &L = c->lp[team ? 2 : 0];
+  const mtp_context::LaunchPlan &L = c->lp[0];
   p.tab_rows = L.tab_rows;
   p.m_doubles = L.m_doubles;
   p.wave_doubles = L.wave_doubles;
@@ -595,8 +573,7 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
       }
       HIP_CHECK(hipEventRecord(c->ev0, st));
     }
-    if (team) HIP_CHECK(mtp_launch_team_kernel(p, L.grid, L.lds_bytes, st));
-    else HIP_CHECK(mtp_launch_wave_kernel(p, L.grid, L.wpb, L.lds_bytes, st));
+    HIP_CHECK(mtp_launch_wave_kernel(p, L.grid, L.wpb, L.lds_bytes, st));
     if (c->timing) {
       HIP_CHECK(hipEventRecord(c->ev1, st));
       c->timed = true;
@@ -710,9 +687,9 @@ int mtp_context_launch_info(const mtp_context *c, int32_t *lds_bytes_per_wave, i
                             int32_t *grid_blocks, int32_t *neighbor_tile)
 {
   if (!c || !c->have_list) return MTP_ERR_STATE;
-  const mtp_context::LaunchPlan &L = c->lp[c->use_team ? 2 : 0];
+  const mtp_context::LaunchPlan &L = c->lp[0];
   if (lds_bytes_per_wave) *lds_bytes_per_wave = L.wave_doubles * 8;   // per atom image
-  if (waves_per_block) *waves_per_block = c->use_team ? -L.wpb : L.wpb;   // negative: wavefronts per ATOM
+  if (waves_per_block) *waves_per_block = L.wpb;
   if (grid_blocks) *grid_blocks = L.grid;
   if (neighbor_tile) *neighbor_tile = c->base.NT;
   return MTP_OK;

@@ -19,6 +19,11 @@ struct MtpDevParams {
   // potential sizes
   int Sp, R, Mu, P, A, B, T, S, C;
   int nslot, nlevels, nseed;
+  // slots are numbered by tensor rank: rank d owns slots [deg_first[d], deg_first[d+1]); the force phase keeps
+  // one block of derivative-polynomial coefficients per slot (1 double for rank 0, 3*d*(d+1)/2 for rank d:
+  // x-, y-, z-derivative, each over the monomials of degree d-1), rank d's blocks starting at deg_coef[d]
+  int deg_first[MTP_PSTRIDE + 2], deg_coef[MTP_PSTRIDE + 2];
+  int coef_total;          // doubles of all coefficient blocks
   double rmin, rmax, scaling, cutsq, inv_span;   // inv_span = 1 / (rmax - rmin)
   // Read-mostly tables, one contiguous blob in HBM that every workgroup copies into the
   // head of its LDS once; offsets in bytes from the blob start (all 8-byte aligned).
@@ -33,6 +38,7 @@ struct MtpDevParams {
   int off_map;             // int[S]
   int off_lin;             // double[S]
   int off_pack;            // int[B] slot | a<<8 | b<<12 | c<<16 | mu<<20
+  int off_coef;            // int[nslot] first coefficient of the slot's block
   int rows_in_lds;
   const MtpRow8 *rows;     // [T] by level, in HBM (always valid)
   const double *species_coeffs;
@@ -58,17 +64,14 @@ struct MtpDevParams {
   int tab_rows;            // table rows = 2*nslot + 3*P 
   int cj_cap;              // capacity of the compacted id list
   int wave_doubles;        // LDS doubles per wavefront
-  int m_doubles;           // doubles of the moment region = max(A, 3*KL*KB, 144)
-  int d_doubles;           // doubles of the adjoint region = max(A, B + 64)
+  int m_doubles;           // doubles of the moment region = max(A, coef_total, 16)
+  int d_doubles;           // doubles of the adjoint region = A
   float inv_mu;            // 1 / Mu
 };
 
 // lane-grid shape for B basics: KL k-lanes x KB basics per lane; -1 when B is too large
 int mtp_pick_shape(int B, int *KL, int *KB);
 hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);
-// workgroup-per-atom variant (4 wavefronts per atom); force calls only
-int mtp_pick_team_shape(int B, int *KL, int *KBW);
-hipError_t mtp_launch_team_kernel(const MtpDevParams &p, int grid, size_t lds, hipStream_t st);
 hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st);
 // radial block of cvec from dbasic (grade calls, after the force kernel)
 hipError_t mtp_launch_cvec_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);

@@ -50,7 +50,7 @@ static __device__ __forceinline__ double wave_sum(double v)
 static __device__ __forceinline__ void lds_add(double *p, double v)
 {
 #ifdef MTP_EXP_NOATOM   // timing experiment only (wrong results): plain store instead of ds_add_f64
-  *(volatile double *) p = v;
+  *p = v;
 #else
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
@@ -91,7 +91,7 @@ template <> struct Butterfly<1> {
 
 struct BlockTables {   // views into the workgroup-shared head of LDS
   const MtpRow8 *rows;
-  const int *level, *slot, *seed_idx, *map, *pack;
+  const int *level, *slot, *seed_idx, *map, *pack, *coef;
   const double *radial, *seed_val, *lin;
 };
 

@@ -21,12 +21,14 @@
 //                   register + immediate; NG-way shuffle sum at the end
 //   4. products     lanes = times rows, one dependency level at a time, moments and
 //                   adjoints in LDS with ds_add_f64 (pair_mtp.cpp:196-233)
-//   5. forces       same lane grid: each lane contracts its adjoints D_k with the analytic
-//                   d(M_k)/d(r_ij) rebuilt from the LDS tables (pair_mtp.cpp:174-191,
-//                   236-246); a butterfly transpose-reduce over the KL k-lanes sums over
-//                   k for KL/4 neighbours per group at once; 16 lanes then scatter
-//                   f_j -= F_ij with fp64 HBM atomics and tally the virial
-//                   (pair_mtp.cpp:248-277)
+//   5. forces       per radial slot s = (mu, nu) the adjoints of its basics are the coefficients of a
+//                   homogeneous polynomial P_s(x, y, z) = sum_k D_k x^a y^b z^c of degree nu, and
+//                   F_ij = sum_s [ dg_s P_s r/|r| + g_s grad P_s ]  (pair_mtp.cpp:174-191, 236-246 summed
+//                   over k), with P_s = (r . grad P_s) / nu (Euler).  Lanes = (neighbour, half): every
+//                   lane raises the monomials of its neighbour degree by degree in registers and
+//                   evaluates the derivative polynomials with coefficients broadcast from LDS (half 0:
+//                   d/dx, half 1: d/dz, d/dy split between the halves by slot); 64 lanes then scatter
+//                   f_j -= F_ij with fp64 HBM atomics and tally the virial (pair_mtp.cpp:248-277)
 //
 // Everything is fp64 (the reference's F_FLOAT); indices are int32.
 #include <hip/hip_runtime.h>
@@ -39,7 +41,7 @@ namespace {
 
 template <int PITCH> struct WaveLds {
   static constexpr int NT = PITCH - 2;
-  double *M, *D, *tab, *nbx, *nby, *nbz, *nbr, *nbi, *red;
+  double *M, *D, *tab, *nbx, *nby, *nbz, *nbr, *nbi;
   int *nbj, *nbjt, *cj;
   unsigned m_addr;   // LDS byte address of M
   __device__ __forceinline__ unsigned addr(const double *ptr) const { return m_addr + 8u * (unsigned) (ptr - M); }
@@ -47,14 +49,13 @@ template <int PITCH> struct WaveLds {
   {
     M = base;
     m_addr = base_addr;
-    D = M + p.m_doubles;   // M region also hosts the exponent-weighted adjoints in phase 5
-    tab = D + p.d_doubles;   // adjoint region: max(A, B + 64) doubles
+    D = M + p.m_doubles;   // M region also hosts the derivative-polynomial coefficients in phase 5
+    tab = D + p.d_doubles;
     nbx = tab + (size_t) p.tab_rows * PITCH;
     nby = nbx + NT;
     nbz = nby + NT;
     nbr = nbz + NT;
     nbi = nbr + NT;
-    red = D + p.B;    // 64 doubles in the tail of the adjoint region: only D[0,B) is live in the force phase
     nbj = reinterpret_cast<int *>(nbi + NT);
     nbjt = nbj + NT;
     cj = nbjt + NT;
@@ -224,15 +225,89 @@ __device__ __forceinline__ void products_backward(const MtpRow8 *rows, const int
   }
 }
 
-template <int KL, int KB, int PITCH, bool GRADE>
+
+// ---- phase 5 helpers ------------------------------------------------------------------------
+// sum_{i<C} coef[i] * m[i]; the coefficient address is the same in all lanes of a half (LDS broadcast)
+template <int C> __device__ __forceinline__ double poly_eval(unsigned coef, const double *m)
+{
+  double a0 = 0.0, a1 = 0.0;
+  constexpr int CH = 8;   // reads per burst
+#pragma unroll
+  for (int i0 = 0; i0 < C; i0 += CH) {
+    double c[CH];
+#pragma unroll
+    for (int u = 0; u < CH; u++)
+      if (i0 + u < C) c[u] = lds_ld(coef, i0 + u);
+#pragma unroll
+    for (int u = 0; u < CH; u++)
+      if (i0 + u < C) {
+        if (u & 1) a1 = fma(c[u], m[i0 + u], a1);
+        else a0 = fma(c[u], m[i0 + u], a0);
+      }
+  }
+  return a0 + a1;
+}
+
+// Slots of tensor rank NU: m[] holds the monomials of degree NU-1 of this lane's neighbour, ordered
+// (a descending, then b descending): idx(a, b, c) = j (j + 1) / 2 + c with j = b + c.  A slot's coefficient
+// block is [d/dx | d/dy | d/dz], each over those monomials.  UA/VA collect sum_s g_s dP_s/dx (half 0) or
+// dP_s/dz (half 1) and the same with dg_s / nu; UB/VB the d/dy terms of the slots this half owns.
+template <int NU, int DEG, int PITCH>
+__device__ __forceinline__ void force_degree(const MtpDevParams &p, unsigned pcol, unsigned pcoef, int part, double x,
+                                             double y, double z, double *m, double &UA, double &VA, double &UB,
+                                             double &VB)
+{
+  if constexpr (NU <= DEG) {
+    constexpr int C = NU * (NU + 1) / 2;   // monomials of degree NU-1
+    if (NU < p.P) {
+      const int s0 = p.deg_first[NU], cnt = p.deg_first[NU + 1] - s0;
+      const double inv_nu = 1.0 / NU;
+      const unsigned dgo = 8u * (unsigned) (p.nslot * PITCH);
+      {
+        unsigned ca = pcoef + 8u * (unsigned) (p.deg_coef[NU] + part * 2 * C);
+        unsigned cg = pcol + 8u * (unsigned) (s0 * PITCH);
+        for (int it = 0; it < cnt; it++) {
+          const double g = lds_ld(cg, 0), dg = lds_ld(cg + dgo, 0);
+          const double G = poly_eval<C>(ca, m);
+          UA = fma(g, G, UA);
+          VA = fma(dg * inv_nu, G, VA);
+          ca += 8u * 3 * C;
+          cg += 8u * PITCH;
+        }
+      }
+      for (int it = 0; 2 * it < cnt; it++) {
+        const int si = 2 * it + part;
+        const bool ok = si < cnt;
+        const int sc = ok ? si : 0;
+        const unsigned cb = pcoef + 8u * (unsigned) (p.deg_coef[NU] + sc * 3 * C + C);
+        const unsigned cg = pcol + 8u * (unsigned) ((s0 + sc) * PITCH);
+        const double g_raw = lds_ld(cg, 0), dg_raw = lds_ld(cg + dgo, 0);
+        const double G = poly_eval<C>(cb, m);
+        const double g = ok ? g_raw : 0.0, dg = ok ? dg_raw : 0.0;
+        UB = fma(g, G, UB);
+        VB = fma(dg * inv_nu, G, VB);
+      }
+      if constexpr (NU < DEG) {
+        // raise the monomials to degree NU: the new a = 0 tail from the old one, then the head times x
+        constexpr int T0 = (NU - 1) * NU / 2;
+#pragma unroll
+        for (int c = 0; c < NU; c++) m[C + c] = y * m[T0 + c];
+        m[C + NU] = z * m[T0 + NU - 1];
+#pragma unroll
+        for (int i = 0; i < C; i++) m[i] *= x;
+        force_degree<NU + 1, DEG, PITCH>(p, pcol, pcoef, part, x, y, z, m, UA, VA, UB, VB);
+      }
+    }
+  }
+}
+
+template <int KL, int KB, int PITCH, bool GRADE, int DEG>
 __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
 {
   constexpr int NT = PITCH - 2;          // neighbours per tile (32 or 16)
   constexpr int NG = 64 / KL;            // neighbour groups in the wavefront
   constexpr int NPG = NT / NG;           // neighbours per group per tile
-  constexpr int BATCH = KL / 4;          // neighbours per group per butterfly
-  constexpr int NBATCH = NPG / BATCH;    // = NT / 16
-  static_assert(NPG % BATCH == 0 && NBATCH >= 1, "tile/batch shape");
+  static_assert(NT == 32, "the force phase maps lanes to (32 neighbours) x (2 halves)");
 
   extern __shared__ double lds[];
   unsigned char *sh = reinterpret_cast<unsigned char *>(lds);
@@ -250,6 +325,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
   bt.map = reinterpret_cast<const int *>(sh + p.off_map);
   bt.lin = reinterpret_cast<const double *>(sh + p.off_lin);
   bt.pack = reinterpret_cast<const int *>(sh + p.off_pack);
+  bt.coef = reinterpret_cast<const int *>(sh + p.off_coef);
   const bool rows_lds = p.rows_in_lds != 0;
 
   const int lane = threadIdx.x & 63;
@@ -264,7 +340,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
 
   // per-lane descriptors of the basics this lane owns (k = kl + KL t): LDS row bases for
   // this lane's neighbour column q; the partner row (dg, next power) is +PITCH
-  unsigned pg[KB], pd[KB], px[KB], py[KB], pz[KB];   // LDS byte addresses
+  unsigned pg[KB], px[KB], py[KB], pz[KB];   // LDS byte addresses
   bool kval[KB];
 #pragma unroll
   for (int t = 0; t < KB; t++) {
@@ -272,17 +348,15 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     kval[t] = k < p.B;
     const int pk = kval[t] ? bt.pack[k] : 0;
     const int a = (pk >> 8) & 15, b = (pk >> 12) & 15, c = (pk >> 16) & 15;
-    // rows: g at slot, dg at ns + slot (bank spread 2*row + column: conflict-free over 16 slots);
-    // px/py/pz point at the row BELOW u^a: u^(a-1), or for a = 0 some finite value that only
-    // ever meets the factor D*a = 0; the power itself is +PITCH
+    // rows: g at slot (dg at ns + slot is read by the force phase); px/py/pz point at the row BELOW u^a
+    // (the power itself is +PITCH)
     pg[t] = w.addr(w.tab + (size_t) (pk & 255) * PITCH + q);
-    pd[t] = w.addr(w.tab + (size_t) (ns + (pk & 255)) * PITCH + q);
     px[t] = w.addr(w.tab + (size_t) (2 * ns + a - 1) * PITCH + q);
     py[t] = w.addr(w.tab + (size_t) (2 * ns + P + b - 1) * PITCH + q);
     pz[t] = w.addr(w.tab + (size_t) (2 * ns + 2 * P + c - 1) * PITCH + q);
     // one finished address per register: stops the optimiser from re-splitting them into
     // base + row offset (which costs a v_add per LDS read in the inner loops)
-    asm volatile("" : "+v"(pg[t]), "+v"(pd[t]), "+v"(px[t]), "+v"(py[t]), "+v"(pz[t]));
+    asm volatile("" : "+v"(pg[t]), "+v"(px[t]), "+v"(py[t]), "+v"(pz[t]));
   }
 
   double tally = 0.0;   // lane 9: energy, lanes 3..8: virial components of this wave's atoms
@@ -427,132 +501,99 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
 
     STAMP(6);   // products backward
     // ---- 5. forces ---------------------------------------------------------------------------
-    // adjoints of the basics times the chain-rule exponents go into the (now free) moment region,
-    // zero-padded to KL*KB: DA/DB/DC, read back with immediate offsets; D_k itself is read from the
-    // adjoint region (lanes past B are masked)
-    constexpr int KP = KL * KB;
-    for (int k = lane; k < KP; k += 64) {
+    // the (now free) moment region receives the coefficient blocks of the derivative polynomials:
+    // basic k = (slot s; a, b, c) puts a D_k at the d/dx coefficient of x^(a-1) y^b z^c, b D_k and c D_k alike
+    for (int k = lane; k < p.coef_total; k += 64) w.M[k] = 0.0;   // monomials the potential does not list
+    wave_fence();
+    for (int k = lane; k < (GRADE ? KL * KB : p.B); k += 64) {
       const bool ok = k < p.B;
       const double d = ok ? w.D[k] : 0.0;
-      const int pk = ok ? bt.pack[k] : 0;
       if (GRADE) p.dbasic[(size_t) ii * p.dpad + k] = d;   // read back by mtp_cvec_kernel
-      w.M[k] = d * (double) ((pk >> 8) & 15);
-      w.M[KP + k] = d * (double) ((pk >> 12) & 15);
-      w.M[2 * KP + k] = d * (double) ((pk >> 16) & 15);
+      if (ok) {
+        const int pk = bt.pack[k];
+        const int a = (pk >> 8) & 15, b = (pk >> 12) & 15, c = (pk >> 16) & 15;
+        const int j = b + c, nu = a + j, C = (nu * (nu + 1)) >> 1;
+        double *blk = w.M + bt.coef[pk & 255];
+        if (nu == 0) blk[0] = d;
+        if (a > 0) blk[((j * (j + 1)) >> 1) + c] = d * (double) a;
+        if (b > 0) blk[C + (((j - 1) * j) >> 1) + c] = d * (double) b;
+        if (c > 0) blk[2 * C + (((j - 1) * j) >> 1) + c - 1] = d * (double) c;
+      }
     }
-    unsigned pdd = w.addr(w.D + kl);
-    asm volatile("" : "+v"(pdd));
-    unsigned pda = w.addr(w.M + kl);
-    asm volatile("" : "+v"(pda));
     wave_fence();
-    // the 16 lanes with kl < BATCH collect: force on i (3), virial (6)
+    STAMP(9);   // coefficient blocks
+    // per-lane partial sums: force on i (3), virial (6)
     double fi0 = 0, fi1 = 0, fi2 = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
-    for (int tile = 0; tile < ntiles; tile++) {
-      const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-      if (ntiles > 1) build_tile<PITCH>(p, bt, w, t0, cnt, ntp, true, xi0, xi1, xi2, i, itype, lane);
-#pragma unroll
-      for (int b = 0; b < NBATCH; b++) {
-        if (b * BATCH * NG < ntp) {
-          double part[KL];
-#pragma unroll
-          for (int u = 0; u < KL; u++) part[u] = 0.0;
-          // stale columns beyond ntp only feed their own (discarded) slots of `part`
-#pragma unroll
-          for (int t = 0; t < KB; t++) {
-            const double Dk_raw = lds_ld(pdd, KL * t), Da = lds_ld(pda, KL * t);   // unconditional (volatile) read
-            const double Dk = kval[t] ? Dk_raw : 0.0;
-            const double Db = lds_ld(pda, KP + KL * t), Dc = lds_ld(pda, 2 * KP + KL * t);
-            constexpr int MC = KL >= 32 ? 2 : (BATCH < 4 ? BATCH : 4);   // columns per burst (8 reads each); wide grids keep bursts short (registers)
-#pragma unroll
-            for (int m0 = 0; m0 < BATCH; m0 += MC) {
-              double g[MC], gd[MC], xm[MC], xa[MC], ym[MC], yb[MC], zm[MC], zc[MC];
-#pragma unroll
-              for (int u = 0; u < MC; u++) {
-                const int o = (b * BATCH + m0 + u) * NG;   // column offset of this lane's neighbour
-                g[u] = lds_ld(pg[t], o);
-                gd[u] = lds_ld(pd[t], o);
-                xm[u] = lds_ld(px[t], o);
-                xa[u] = lds_ld(px[t], PITCH + o);
-                ym[u] = lds_ld(py[t], o);
-                yb[u] = lds_ld(py[t], PITCH + o);
-                zm[u] = lds_ld(pz[t], o);
-                zc[u] = lds_ld(pz[t], PITCH + o);
-              }
-              __builtin_amdgcn_sched_barrier(0);   // the whole burst issues before its math
-#pragma unroll
-              for (int u = 0; u < MC; u++) {
-                const int mm = m0 + u;
-                const double yz = yb[u] * zc[u], xz = xa[u] * zc[u], xy = xa[u] * yb[u];
-                part[4 * mm + 0] += (Dk * gd[u]) * (xa[u] * yz);
-                part[4 * mm + 1] += (Da * g[u]) * (xm[u] * yz);
-                part[4 * mm + 2] += (Db * g[u]) * (ym[u] * xz);
-                part[4 * mm + 3] += (Dc * g[u]) * (zm[u] * xy);
-              }
-              if (m0 + MC < BATCH) __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_sched_barrier(0);   // one basic's reads in flight at a time (register pressure)
+    {
+      const int n = lane & 31, part = lane >> 5;
+      unsigned pcol = w.addr(w.tab + n);
+      asm volatile("" : "+v"(pcol));
+      for (int tile = 0; tile < ntiles; tile++) {
+        const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
+        if (ntiles > 1) build_tile<PITCH>(p, bt, w, t0, cnt, ntp, true, xi0, xi1, xi2, i, itype, lane);
+        // columns past ntp hold stale (finite or not) data: their lanes are masked at the end
+        const double x = w.nbx[n], y = w.nby[n], z = w.nbz[n], inv = w.nbi[n];
+        double UA = 0.0, VA = 0.0, UB = 0.0, VB = 0.0, S0 = 0.0;
+        {   // rank 0: P_s = D_k, no gradient
+          unsigned cg = pcol + 8u * (unsigned) (ns * PITCH);
+          for (int sidx = 0; sidx < p.deg_first[1]; sidx++) {
+            S0 = fma(lds_ld(cg, 0), w.M[p.deg_coef[0] + sidx], S0);
+            cg += 8u * PITCH;
           }
-          Butterfly<KL>::run(part, lane);
-          w.red[lane] = part[0];   // lane (q, kl): value kl of group q
-          wave_fence();
-          const int n = q + NG * (b * BATCH + kl);
-          if (kl < BATCH && n < nt) {
-            const double *rq = w.red + q * KL + 4 * kl;
-            const double sr = rq[0] * w.nbi[n];
-            const double rx = w.nbx[n], ry = w.nby[n], rz = w.nbz[n];
-            const double Fx = sr * rx + rq[1];
-            const double Fy = sr * ry + rq[2];
-            const double Fz = sr * rz + rq[3];
-            const size_t j = (size_t) w.nbj[n];
-#ifndef MTP_EXP_NOSCATTER   // timing experiment only (wrong results)
-            unsafeAtomicAdd(&p.f[3 * j + 0], -Fx);   // pair_mtp.cpp:252-254
-            unsafeAtomicAdd(&p.f[3 * j + 1], -Fy);
-            unsafeAtomicAdd(&p.f[3 * j + 2], -Fz);
-#else
-            if (Fx + Fy + Fz == 12345.678) p.f[3 * j] = Fx;   // keeps the values live
-#endif
-            fi0 += Fx;
-            fi1 += Fy;
-            fi2 += Fz;
-            if (p.vflag) {   // pair_mtp.cpp:257-277
-              v0 -= Fx * rx;
-              v1 -= Fy * ry;
-              v2 -= Fz * rz;
-              v3 -= (Fx * ry + Fy * rx) * 0.5;
-              v4 -= (Fx * rz + Fz * rx) * 0.5;
-              v5 -= (Fy * rz + Fz * ry) * 0.5;
-            }
-          }
-          wave_fence();
         }
+        double mono[DEG * (DEG + 1) / 2];
+        mono[0] = 1.0;
+        force_degree<1, DEG, PITCH>(p, pcol, w.m_addr, part, x, y, z, mono, UA, VA, UB, VB);
+        // sum_s dg_s P_s = r . sum_s (dg_s / nu) grad P_s  (+ rank 0), shared by both halves
+        double S = (part ? z : x) * VA + y * VB + (part ? 0.0 : S0);
+        S += shfl_xor_f64(S, 32);
+        UB += shfl_xor_f64(UB, 32);
+        const double sr = S * inv;
+        const bool valid = n < nt;
+        const double Fa = valid ? fma(sr, part ? z : x, UA) : 0.0;   // half 0: F_x, half 1: F_z
+        const double Fy = valid && part == 0 ? fma(sr, y, UB) : 0.0;
+        const double Fx = part ? 0.0 : Fa, Fz = part ? Fa : 0.0;
+        if (valid) {
+          const size_t j = (size_t) w.nbj[n];
+          unsafeAtomicAdd(&p.f[3 * j + (part ? 2 : 0)], -Fa);   // pair_mtp.cpp:252-254
+          if (part == 0) unsafeAtomicAdd(&p.f[3 * j + 1], -Fy);
+        }
+        fi0 += Fx;
+        fi1 += Fy;
+        fi2 += Fz;
+        if (p.vflag && valid) {   // pair_mtp.cpp:257-277 (linear in F: each half tallies its components)
+          v0 -= Fx * x;
+          v1 -= Fy * y;
+          v2 -= Fz * z;
+          v3 -= (Fx * y + Fy * x) * 0.5;
+          v4 -= (Fx * z + Fz * x) * 0.5;
+          v5 -= (Fy * z + Fz * y) * 0.5;
+        }
+        if (ntiles > 1) wave_fence();
       }
     }
     STAMP(7);   // forces
-    // ---- per-atom totals: 9 values x 16 lanes through LDS, lane v sums value v -------------
-    if (kl < BATCH) {
-      const int li = q * BATCH + kl;   // 0..15
-      double *fin = w.M;               // the moment region is free again (m_doubles >= 144)
-      fin[0 * 16 + li] = fi0;
-      fin[1 * 16 + li] = fi1;
-      fin[2 * 16 + li] = fi2;
-      fin[3 * 16 + li] = v0;
-      fin[4 * 16 + li] = v1;
-      fin[5 * 16 + li] = v2;
-      fin[6 * 16 + li] = v3;
-      fin[7 * 16 + li] = v4;
-      fin[8 * 16 + li] = v5;
+    // ---- per-atom totals over the 64 lanes: lane v < 9 ends up with value v --------------------
+    double tot;
+    if (p.vflag) {
+      double part16[16] = {fi0, fi1, fi2, v0, v1, v2, v3, v4, v5, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      Butterfly<16>::run(part16, lane);
+      tot = part16[0];
+    } else {
+      double part4[4] = {fi0, fi1, fi2, 0.0};
+      Butterfly<4>::run(part4, lane);
+      tot = part4[0];
+      tot += shfl_xor_f64(tot, 4);
+      tot += shfl_xor_f64(tot, 8);
     }
-    wave_fence();
+    tot += shfl_xor_f64(tot, 16);
+    tot += shfl_xor_f64(tot, 32);
     if (lane < 9) {
-      const double *r = w.M + 16 * lane;
-      double s = 0.0;
-#pragma unroll
-      for (int u = 0; u < 16; u += 4) s += (r[u] + r[u + 1]) + (r[u + 2] + r[u + 3]);
       if (lane < 3) {
-        unsafeAtomicAdd(&p.f[3 * (size_t) i + lane], s);   // pair_mtp.cpp:248-250
+        unsafeAtomicAdd(&p.f[3 * (size_t) i + lane], tot);   // pair_mtp.cpp:248-250
       } else if (p.vflag) {
-        tally += s;
-        if ((p.vflag & 4) && p.vatom) p.vatom[6 * (size_t) i + (lane - 3)] += s;
+        tally += tot;
+        if ((p.vflag & 4) && p.vatom) p.vatom[6 * (size_t) i + (lane - 3)] += tot;
       }
     }
     if (lane == 9) {
@@ -664,27 +705,36 @@ __global__ void __launch_bounds__(256) mtp_colsum_kernel(const double *__restric
   unsafeAtomicAdd(&coeff_ders[c], s);
 }
 
-template <int KL, int KB, int PITCH, bool GRADE>
+template <int KL, int KB, int PITCH, bool GRADE, int DEG>
 hipError_t launch_one(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
 {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mtp_wave_kernel<KL, KB, PITCH, GRADE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mtp_wave_kernel<KL, KB, PITCH, GRADE, DEG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((mtp_wave_kernel<KL, KB, PITCH, GRADE>), dim3(grid), dim3(64 * wpb), lds, st, p);
+  hipLaunchKernelGGL((mtp_wave_kernel<KL, KB, PITCH, GRADE, DEG>), dim3(grid), dim3(64 * wpb), lds, st, p);
   return hipGetLastError();
 }
 
+template <int KL, int KB, int DEG> hipError_t launch_grade(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
+{
+  // only the 32-neighbour tile (pitch 34) is instantiated; the grade variant is its own instantiation so the
+  // force-only kernel keeps its register budget
+  return p.grade_flag ? launch_one<KL, KB, 34, true, DEG>(p, grid, wpb, lds, st)
+                      : launch_one<KL, KB, 34, false, DEG>(p, grid, wpb, lds, st);
+}
+
+// DEG = highest tensor rank the unrolled force phase covers (monomials up to degree DEG-1 in registers):
+// narrow lane grids (B <= 160) come with ranks <= 6 in the MLIP level tables, wide ones with ranks <= 8;
+// DEG = 11 is the general instantiation (the loader caps the rank at 11).
 template <int KL, int KB> hipError_t launch_pitch(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
 {
-  // only the 32-neighbour tile (pitch 34) is instantiated: hipcc 7.2 rejects the pitch-18 and
-  // KB = 1 shapes with a machine-verifier error ("Operand has incorrect register class")
-  // the grade variant is its own instantiation so the force-only kernel keeps its register budget
-  return p.grade_flag ? launch_one<KL, KB, 34, true>(p, grid, wpb, lds, st)
-                      : launch_one<KL, KB, 34, false>(p, grid, wpb, lds, st);
+  constexpr int DLOW = KL == 16 ? 6 : 8;
+  if (p.P - 1 <= DLOW) return launch_grade<KL, KB, DLOW>(p, grid, wpb, lds, st);
+  return launch_grade<KL, KB, 11>(p, grid, wpb, lds, st);
 }
 
 }   // namespace

@@ -446,22 +446,38 @@ int mtp_potential::finalize(std::string &err)
         seed_val.push_back(linear_coeffs[last[m]]);
       }
   }
+  // radial slots = distinct (mu, nu) of the basics, numbered by tensor rank nu, then mu
   slot_of.assign((size_t) Mu * P, -1);
-  slot_count = 0;
-  basic_pack.resize((size_t) B);
   for (int i = 0; i < B; i++) {
     const int32_t *q = &alpha_index_basic[4 * (size_t) i];
-    int nu = q[1] + q[2] + q[3];
-    int32_t &s = slot_of[(size_t) q[0] * P + nu];
-    if (s < 0) s = slot_count++;
-    if (s > 255) {
-      err = "more than 256 distinct (mu, nu) radial slots";
-      return MTP_ERR_LIMIT;
-    }
     if (q[0] > 15) {
       err = "radial function index above 15 is not supported";
       return MTP_ERR_LIMIT;
     }
+    slot_of[(size_t) q[0] * P + (q[1] + q[2] + q[3])] = -2;   // used, not yet numbered
+  }
+  slot_count = 0;
+  slot_coef_off.clear();
+  coef_total = 0;
+  for (int nu = 0; nu < 14; nu++) {
+    deg_first[nu] = slot_count;
+    deg_coef[nu] = coef_total;
+    if (nu >= P) continue;
+    for (int mu = 0; mu < Mu; mu++)
+      if (slot_of[(size_t) mu * P + nu] == -2) {
+        slot_of[(size_t) mu * P + nu] = slot_count++;
+        slot_coef_off.push_back(coef_total);
+        coef_total += nu == 0 ? 1 : 3 * (nu * (nu + 1) / 2);
+      }
+  }
+  if (slot_count > 256) {
+    err = "more than 256 distinct (mu, nu) radial slots";
+    return MTP_ERR_LIMIT;
+  }
+  basic_pack.resize((size_t) B);
+  for (int i = 0; i < B; i++) {
+    const int32_t *q = &alpha_index_basic[4 * (size_t) i];
+    const int s = slot_of[(size_t) q[0] * P + (q[1] + q[2] + q[3])];
     basic_pack[i] = s | (q[1] << 8) | (q[2] << 12) | (q[3] << 16) | (q[0] << 20);
   }
   return MTP_OK;

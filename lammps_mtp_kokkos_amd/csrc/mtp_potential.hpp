@@ -36,6 +36,12 @@ struct mtp_potential {
   // distinct (mu, nu) pairs used by the basics -> slot; slot_of[mu*P+nu] or -1
   std::vector<int32_t> slot_of;
   int slot_count = 0;
+  // slots sorted by tensor rank nu (then mu): rank d owns slots [deg_first[d], deg_first[d+1]);
+  // slot_coef_off[s] = first double of the slot's derivative-polynomial coefficient block,
+  // deg_coef[d] = that of rank d's first slot, coef_total = doubles of all blocks
+  std::vector<int32_t> slot_coef_off;
+  int deg_first[14] = {0}, deg_coef[14] = {0};
+  int coef_total = 0;
   // per basic: slot | a<<8 | b<<12 | c<<16 | mu<<20 (what a lane needs per k)
   std::vector<int32_t> basic_pack;
   // adjoint seeds: D[idx] = val (last mapping entry wins, pair_mtp.cpp:217-218)

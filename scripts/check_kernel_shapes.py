@@ -24,7 +24,9 @@ def run(c):
     res = []
     for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?VGPRs Spill: (\d+)", out, re.S):
         if "mtp_wave_kernel" in m.group(1):
-            res.append(("grade" if "ELb1E" in m.group(1) else "force", int(m.group(2)), int(m.group(3))))
+            deg = re.search(r"ELb[01]ELi(\d+)E", m.group(1))
+            res.append((("grade" if "ELb1E" in m.group(1) else "force") + "/deg" + (deg.group(1) if deg else "?"),
+                        int(m.group(2)), int(m.group(3))))
     return c, ("ERR" if "error" in out else "ok"), res
 
 

@@ -32,8 +32,8 @@ for it in range(3):
     ctx.synchronize()
     L.mtp_debug_read_stamps(ctx.h, buf)
 names = ["loop head", "compaction", "tile tables", "basic moments", "products fwd", "energy+seeds", "products bwd",
-         "forces", "totals"]
-v = np.array(list(buf)[:9], dtype=float)
+         "forces", "totals", "coef blocks"]
+v = np.array(list(buf)[:10], dtype=float)
 print("launch", ctx.launch_info())
 for n, c in zip(names, v):
     print("%-14s %6.2f %%   %8.0f cycles/atom" % (n, 100 * c / v.sum(), c / s.nlocal))
