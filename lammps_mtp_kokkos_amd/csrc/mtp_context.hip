@@ -82,7 +82,7 @@ struct mtp_context {
   DevBuf<unsigned long long> d_stamps;
   // launch geometry
   struct LaunchPlan {
-    int wpb = 1, grid = 1, wave_doubles = 0, tab_rows = 0, g_doubles = 0, m_doubles = 0;
+    int wpb = 1, grid = 1, wave_doubles = 0, tab_rows = 0, g_doubles = 0, m_doubles = 0, ov_doubles = 0;
     size_t lds_bytes = 0;
   } lp[2];   // [0] force calls (wavefront per atom), [1] candidate-vector kernel of grade calls
   DevBuf<double> d_cvec, d_ainv_pad, d_dbasic;
@@ -116,7 +116,9 @@ void mtp_context::plan()
     L.g_doubles = 0;
     L.m_doubles = std::max(std::max(A, p.coef_total), 16);   // moments, later the derivative-polynomial coefficients
     const int d_doubles = A;
-    const size_t dbl = (size_t) d_doubles + L.m_doubles + (size_t) L.tab_rows * (nt + 2) + 5 * (size_t) nt;
+    // coordinate-power rows and moments/adjoints share one overlay (never live together)
+    L.ov_doubles = std::max(3 * P * (nt + 2), d_doubles + L.m_doubles);
+    const size_t dbl = (size_t) 2 * p.slot_count * (nt + 2) + L.ov_doubles + 5 * (size_t) nt;
     const size_t ints = (size_t) 2 * nt + cap;
     const size_t wb = (dbl * 8 + ints * 4 + 15) / 16 * 16;
     // waves per CU for w waves per workgroup; registers allow 8 (2 per SIMD)
@@ -130,8 +132,8 @@ void mtp_context::plan()
     int best_w = 0, best = 0;
     for (int w = 1; w <= wmax; w++) {
       int v = waves_per_cu(w);
-      // prefer occupancy; at equal occupancy more waves per workgroup when the shared blob is big
-      if (v > best || (v == best && v > 0 && blob > 16384 && w > best_w)) {
+      // prefer occupancy; at equal occupancy more waves per workgroup (fewer copies of the table blob)
+      if (v > best || (v == best && v > 0 && w > best_w)) {
         best = v;
         best_w = w;
       }
@@ -326,7 +328,7 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     bb.off_map = put(pot->alpha_moment_mapping.data(), pot->alpha_moment_mapping.size() * sizeof(int32_t));
     bb.off_lin = put(pot->linear_coeffs.data(), pot->linear_coeffs.size() * sizeof(double));
     bb.off_pack = put(pot->basic_pack.data(), pot->basic_pack.size() * sizeof(int32_t));
-    bb.off_coef = put(pot->slot_coef_off.data(), pot->slot_coef_off.size() * sizeof(int32_t));
+    bb.off_coef = put(pot->basic_tgt.data(), pot->basic_tgt.size() * sizeof(int32_t));
     blob.resize((blob.size() + 15) / 16 * 16, 0);
     bb.blob_bytes = (int) blob.size();
     c->d_blob.upload(blob.data(), blob.size(), st);
@@ -361,6 +363,7 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     b.C = pot->coeff_count;
     b.nslot = pot->slot_count;
     b.coef_total = pot->coef_total;
+    b.coef_dense = pot->coef_dense;
     for (int d = 0; d <= MTP_PSTRIDE; d++) {
       b.deg_first[d] = pot->deg_first[d];
       b.deg_coef[d] = pot->deg_coef[d];
@@ -560,6 +563,7 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
   const mtp_context::LaunchPlan &L = c->lp[0];
   p.tab_rows = L.tab_rows;
   p.m_doubles = L.m_doubles;
+  p.ov_doubles = L.ov_doubles;
   p.wave_doubles = L.wave_doubles;
   p.cvec = grade_flag ? c->d_cvec.ptr : nullptr;
   p.cpad = c->cpad;

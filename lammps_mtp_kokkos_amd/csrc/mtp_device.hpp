@@ -24,6 +24,7 @@ struct MtpDevParams {
   // x-, y-, z-derivative, each over the monomials of degree d-1), rank d's blocks starting at deg_coef[d]
   int deg_first[MTP_PSTRIDE + 2], deg_coef[MTP_PSTRIDE + 2];
   int coef_total;          // doubles of all coefficient blocks
+  int coef_dense;          // every coefficient has a source basic (no zero fill)
   double rmin, rmax, scaling, cutsq, inv_span;   // inv_span = 1 / (rmax - rmin)
   // Read-mostly tables, one contiguous blob in HBM that every workgroup copies into the
   // head of its LDS once; offsets in bytes from the blob start (all 8-byte aligned).
@@ -38,7 +39,7 @@ struct MtpDevParams {
   int off_map;             // int[S]
   int off_lin;             // double[S]
   int off_pack;            // int[B] slot | a<<8 | b<<12 | c<<16 | mu<<20
-  int off_coef;            // int[nslot] first coefficient of the slot's block
+  int off_coef;            // int2[B] scatter targets of each basic's adjoint: {tx | ty << 16, tz | fa << 16 | fb << 20 | fc << 24}
   int rows_in_lds;
   const MtpRow8 *rows;     // [T] by level, in HBM (always valid)
   const double *species_coeffs;
@@ -61,7 +62,8 @@ struct MtpDevParams {
   int eflag, vflag, grade_flag;
   // launch geometry
   int NT;                  // neighbours per LDS tile: 32 or 16 (table row pitch = NT + 2 doubles)
-  int tab_rows;            // table rows = 2*nslot + 3*P 
+  int tab_rows;            // table rows = 2*nslot + 3*P (candidate-vector kernel: 4*P + R)
+  int ov_doubles;          // force kernel: doubles of the overlay = max(3*P*(NT+2), m_doubles + d_doubles)
   int cj_cap;              // capacity of the compacted id list
   int wave_doubles;        // LDS doubles per wavefront
   int m_doubles;           // doubles of the moment region = max(A, coef_total, 16)

@@ -40,11 +40,57 @@ static __device__ __forceinline__ double uniform_f64(double v)   // v is wave-un
   return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
 }
 
-static __device__ __forceinline__ double wave_sum(double v)
+// Cross-lane moves inside a row of 16 lanes on the VALU (DPP), no LDS traffic: the partner of lane l is
+// l^1, l^2 (quad permutes), l^7 (row_half_mirror) or l^15 (row_mirror).  Any of them flips exactly the
+// lane bit a butterfly step splits on (bit 0, 1, 2, 3), which is all the reductions below need.
+template <int CTRL> static __device__ __forceinline__ double dpp_f64(double v)
 {
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) v += shfl_xor_f64(v, s);
-  return v;
+  const long long b = __double_as_longlong(v);
+  int lo = (int) b, hi = (int) (b >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __longlong_as_double((long long) (((unsigned long long) (unsigned) hi << 32) | (unsigned) lo));
+}
+// value of the lane that differs in bit log2(H) (and possibly lower bits); H >= 16 goes through ds_bpermute
+template <int H> static __device__ __forceinline__ double partner_f64(double v)
+{
+  if constexpr (H == 1) return dpp_f64<0xB1>(v);        // quad_perm [1,0,3,2]
+  else if constexpr (H == 2) return dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  else if constexpr (H == 4) return dpp_f64<0x141>(v);  // row_half_mirror
+  else if constexpr (H == 8) return dpp_f64<0x140>(v);  // row_mirror
+  else return shfl_xor_f64(v, H);
+}
+
+// v + (value of lane l^16) and v + (value of lane l^32) with gfx950's row / half swaps: with both operands equal
+// to v, v_permlane16_swap leaves {rows 0,0,2,2} in one register and {rows 1,1,3,3} in the other (measured
+// lane maps: scripts/probes/permlane_probe.hip), so their sum is the pair sum in every lane, in the same
+// operand order everywhere; v_permlane32_swap does the same for the wavefront halves.  No LDS traffic.
+static __device__ __forceinline__ double pair_sum16(double v)
+{
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned) b, hi = (unsigned) (b >> 32);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __longlong_as_double((long long) (((unsigned long long) c[0] << 32) | a[0])) +
+      __longlong_as_double((long long) (((unsigned long long) c[1] << 32) | a[1]));
+}
+static __device__ __forceinline__ double pair_sum32(double v)
+{
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned) b, hi = (unsigned) (b >> 32);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __longlong_as_double((long long) (((unsigned long long) c[0] << 32) | a[0])) +
+      __longlong_as_double((long long) (((unsigned long long) c[1] << 32) | a[1]));
+}
+
+static __device__ __forceinline__ double wave_sum(double v)   // same bits in every lane
+{
+  v += partner_f64<1>(v);
+  v += partner_f64<2>(v);
+  v += partner_f64<4>(v);
+  v += partner_f64<8>(v);   // every lane: sum of its row of 16
+  return pair_sum32(pair_sum16(v));
 }
 
 static __device__ __forceinline__ void lds_add(double *p, double v)
@@ -70,7 +116,7 @@ static __device__ __forceinline__ double lds_ld(unsigned base, int off_doubles) 
 
 // Butterfly transpose-reduce over the lane bits below N: every lane enters with N partial
 // sums v[0..N); on exit v[0] of lane l holds entry (l mod N) summed over the N lanes that
-// differ from l only in those bits.  N-1 adds and N-1 exchanges instead of N*log2(N).
+// differ from l only in those bits (steps within a row of 16 lanes run on DPP).  N-1 adds and N-1 exchanges instead of N*log2(N).
 template <int N> struct Butterfly {
   static __device__ __forceinline__ void run(double *v, int lane)
   {
@@ -80,7 +126,7 @@ template <int N> struct Butterfly {
     for (int i = 0; i < H; i++) {
       const double keep = hi ? v[i + H] : v[i];
       const double send = hi ? v[i] : v[i + H];
-      v[i] = keep + shfl_xor_f64(send, H);
+      v[i] = keep + partner_f64<H>(send);
     }
     Butterfly<H>::run(v, lane);
   }

@@ -39,6 +39,10 @@
 
 namespace {
 
+#ifndef MTP_PU
+#define MTP_PU 4   // times rows in flight per lane in the product passes
+#endif
+
 template <int PITCH> struct WaveLds {
   static constexpr int NT = PITCH - 2;
   double *M, *D, *tab, *nbx, *nby, *nbz, *nbr, *nbi;
@@ -47,11 +51,14 @@ template <int PITCH> struct WaveLds {
   __device__ __forceinline__ unsigned addr(const double *ptr) const { return m_addr + 8u * (unsigned) (ptr - M); }
   __device__ __forceinline__ WaveLds(double *base, unsigned base_addr, const MtpDevParams &p)
   {
-    M = base;
-    m_addr = base_addr;
-    D = M + p.m_doubles;   // M region also hosts the derivative-polynomial coefficients in phase 5
-    tab = D + p.d_doubles;
-    nbx = tab + (size_t) p.tab_rows * PITCH;
+    // [g rows | dg rows | overlay | neighbour arrays]; the overlay holds the coordinate-power rows from
+    // the tile build to the end of the basic-moment pass, and the moments / adjoints (later the
+    // derivative-polynomial coefficients) from there on -- the two are never live together
+    tab = base;
+    M = tab + (size_t) 2 * p.nslot * PITCH;
+    m_addr = base_addr + 8u * (unsigned) (2 * p.nslot * PITCH);
+    D = M + p.m_doubles;
+    nbx = M + p.ov_doubles;
     nby = nbx + NT;
     nbz = nby + NT;
     nbr = nbz + NT;
@@ -66,8 +73,8 @@ template <int PITCH> struct WaveLds {
 // neighbour-group count with dummy neighbours sitting exactly on the cutoff (g = dg = 0).
 template <int PITCH>
 __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTables &bt, const WaveLds<PITCH> &w,
-                                           int t0, int cnt, int ntp, bool gather, double xi0, double xi1,
-                                           double xi2, int i, int itype, int lane)
+                                           int t0, int cnt, int ntp, bool gather, bool powers, double xi0,
+                                           double xi1, double xi2, int i, int itype, int lane)
 {
   if (gather) {
     if (lane < ntp) {
@@ -90,84 +97,108 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
     }
     wave_fence();
   }
+  // lanes = (neighbour n, half h): one pass over the tile.  The Chebyshev values q_k(r) and derivatives are
+  // shared by all radial functions of the neighbour; half h contracts them for mu = h, h+2, ... and writes
+  // the g / dg rows of those mu; the coordinate-power rows are split x,y | z between the halves.
   const int Mu = p.Mu, P = p.P, R = p.R;
   const double mult = 2.0 * p.inv_span;
-  for (int idx = lane; idx < ntp * Mu; idx += 64) {
-    const int n = __float2int_rz((idx + 0.5f) * p.inv_mu), mu = idx - n * Mu;
+  const int n = lane & 31, h = lane >> 5;
+  if (n < ntp) {
     const double r = w.nbr[n], inv = w.nbi[n];
     const int jt = w.nbjt[n];
-    // slot ids of this mu for nu = 0..11 (padded with -1 on the host): three 16-byte LDS reads,
-    // issued before the recurrence so their latency hides under it
-    const int4 *sl4 = reinterpret_cast<const int4 *>(bt.slot + mu * MTP_PSTRIDE);
-    const int4 sa = sl4[0], sb = sl4[1], sc = sl4[2];
-    const int sv[MTP_PSTRIDE] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w, sc.x, sc.y, sc.z, sc.w};
-    const double *c = bt.radial + ((itype * p.Sp + jt) * Mu + mu) * R;
-    // Chebyshev values/derivatives by recurrence, contracted on the fly
     const double d = r - p.rmax;
     const double ksi = (2.0 * r - (p.rmin + p.rmax)) * p.inv_span;
-    double q0 = p.scaling * (d * d), q1 = p.scaling * (ksi * d * d);
-    double e0 = p.scaling * 2.0 * d, e1 = p.scaling * (mult * d * d + 2.0 * ksi * d);
-    double val, der;
-    if (R == 8) {   // the MLIP default: all eight coefficients in one burst of 16-byte reads, straight-line recurrence
-      const double2 *c2 = reinterpret_cast<const double2 *>(c);
-      const double2 c01 = c2[0], c23 = c2[1], c45 = c2[2], c67 = c2[3];
-      const double cc[8] = {c01.x, c01.y, c23.x, c23.y, c45.x, c45.y, c67.x, c67.y};
-      val = cc[0] * q0 + cc[1] * q1;
-      der = cc[0] * e0 + cc[1] * e1;
+    double *col = w.tab + n;
+    if (R == 8) {   // the MLIP default: basis in registers, coefficients in bursts of 16-byte reads
+      double qv[8], ev[8];
+      qv[0] = p.scaling * (d * d);
+      qv[1] = p.scaling * (ksi * d * d);
+      ev[0] = p.scaling * 2.0 * d;
+      ev[1] = p.scaling * (mult * d * d + 2.0 * ksi * d);
 #pragma unroll
-      for (int ri = 2; ri < 8; ri++) {
-        const double q2 = 2.0 * ksi * q1 - q0;
-        const double e2 = 2.0 * (mult * q1 + ksi * e1) - e0;
-        val += cc[ri] * q2;
-        der += cc[ri] * e2;
-        q0 = q1;
-        q1 = q2;
-        e0 = e1;
-        e1 = e2;
+      for (int ri = 2; ri < 8; ri++) {   // mtp_rb_chevbyshev_basis.cpp:29-54
+        qv[ri] = 2.0 * ksi * qv[ri - 1] - qv[ri - 2];
+        ev[ri] = 2.0 * (mult * qv[ri - 1] + ksi * ev[ri - 1]) - ev[ri - 2];
+      }
+      for (int mu = h; mu < Mu; mu += 2) {
+        const int4 *sl4 = reinterpret_cast<const int4 *>(bt.slot + mu * MTP_PSTRIDE);
+        const int4 sa = sl4[0], sb = sl4[1], sc = sl4[2];
+        const int sv[MTP_PSTRIDE] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w, sc.x, sc.y, sc.z, sc.w};
+        const double2 *c2 = reinterpret_cast<const double2 *>(bt.radial + ((itype * p.Sp + jt) * Mu + mu) * 8);
+        const double2 c01 = c2[0], c23 = c2[1], c45 = c2[2], c67 = c2[3];
+        const double cc[8] = {c01.x, c01.y, c23.x, c23.y, c45.x, c45.y, c67.x, c67.y};
+        double val = cc[0] * qv[0], der = cc[0] * ev[0];
+#pragma unroll
+        for (int ri = 1; ri < 8; ri++) {
+          val = fma(cc[ri], qv[ri], val);
+          der = fma(cc[ri], ev[ri], der);
+        }
+        double rp = 1.0;
+#pragma unroll
+        for (int nu = 0; nu < MTP_PSTRIDE; nu++) {
+          if (nu < P) {
+            const int sidx = sv[nu];
+            const double g = val * rp;
+            if (sidx >= 0) {
+              col[sidx * PITCH] = g;                                       // f_mu / r^nu
+              col[(p.nslot + sidx) * PITCH] = der * rp - nu * g * inv;     // d/dr (f_mu / r^nu)
+            }
+            rp *= inv;
+          }
+        }
       }
     } else {
-      val = c[0] * q0;
-      der = c[0] * e0;
-      if (R > 1) {
-        val += c[1] * q1;
-        der += c[1] * e1;
-      }
-      for (int ri = 2; ri < R; ri++) {
-        const double q2 = 2.0 * ksi * q1 - q0;
-        const double e2 = 2.0 * (mult * q1 + ksi * e1) - e0;
-        val += c[ri] * q2;
-        der += c[ri] * e2;
-        q0 = q1;
-        q1 = q2;
-        e0 = e1;
-        e1 = e2;
-      }
-    }
-    double *col = w.tab + n;
-    double rp = 1.0;
-#pragma unroll
-    for (int nu = 0; nu < MTP_PSTRIDE; nu++) {
-      if (nu < P) {
-        const int sidx = sv[nu];
-        const double g = val * rp;
-        if (sidx >= 0) {
-          col[sidx * PITCH] = g;                                       // f_mu / r^nu
-          col[(p.nslot + sidx) * PITCH] = der * rp - nu * g * inv;     // d/dr (f_mu / r^nu)
+      for (int mu = h; mu < Mu; mu += 2) {
+        const int *sl = bt.slot + mu * MTP_PSTRIDE;
+        const double *c = bt.radial + ((itype * p.Sp + jt) * Mu + mu) * R;
+        double q0 = p.scaling * (d * d), q1 = p.scaling * (ksi * d * d);
+        double e0 = p.scaling * 2.0 * d, e1 = p.scaling * (mult * d * d + 2.0 * ksi * d);
+        double val = c[0] * q0, der = c[0] * e0;
+        if (R > 1) {
+          val += c[1] * q1;
+          der += c[1] * e1;
         }
-        rp *= inv;
+        for (int ri = 2; ri < R; ri++) {
+          const double q2 = 2.0 * ksi * q1 - q0;
+          const double e2 = 2.0 * (mult * q1 + ksi * e1) - e0;
+          val += c[ri] * q2;
+          der += c[ri] * e2;
+          q0 = q1;
+          q1 = q2;
+          e0 = e1;
+          e1 = e2;
+        }
+        double rp = 1.0;
+        for (int nu = 0; nu < P; nu++) {
+          const int sidx = sl[nu];
+          const double g = val * rp;
+          if (sidx >= 0) {
+            col[sidx * PITCH] = g;
+            col[(p.nslot + sidx) * PITCH] = der * rp - nu * g * inv;
+          }
+          rp *= inv;
+        }
       }
     }
-  }
-  for (int idx = lane; idx < ntp * 3; idx += 64) {
-    const int n = __float2int_rz((idx + 0.5f) * (1.0f / 3.0f)), ax = idx - 3 * n;
-    const double u = ax == 0 ? w.nbx[n] : (ax == 1 ? w.nby[n] : w.nbz[n]);
-    // rows of one axis: [q] = u^q
-    double *col = w.tab + (size_t) (2 * p.nslot + ax * P) * PITCH + n;
-    double cur = 1.0;
-    col[0] = 1.0;
-    for (int q = 1; q < P; q++) {
-      cur *= u;
-      col[q * PITCH] = cur;
+    if (powers) {   // rows of one axis: [q] = u^q
+      const double u0 = h == 0 ? w.nbx[n] : w.nbz[n];
+      double *pc = col + (size_t) (2 * p.nslot + (h == 0 ? 0 : 2 * P)) * PITCH;
+      double cur = 1.0;
+      pc[0] = 1.0;
+      for (int q = 1; q < P; q++) {
+        cur *= u0;
+        pc[q * PITCH] = cur;
+      }
+      if (h == 0) {
+        const double u1 = w.nby[n];
+        pc += (size_t) P * PITCH;
+        cur = 1.0;
+        pc[0] = 1.0;
+        for (int q = 1; q < P; q++) {
+          cur *= u1;
+          pc[q * PITCH] = cur;
+        }
+      }
     }
   }
   wave_fence();
@@ -177,20 +208,21 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
 // never write an operand of the same level, so four rows per lane are in flight before their
 // ds_add_f64 issue.  (Two call sites, LDS-resident and HBM-resident rows: a select between the two
 // pointers would go through a generic pointer, which hipcc 7.2 miscompiles on gfx950.)
+template <int U>
 __device__ __forceinline__ void products_forward(const MtpRow8 *rows, const int *level, int nlevels, double *M,
                                                  int lane)
 {
   for (int l = 0; l < nlevels; l++) {
     const int end = level[l + 1];
-    for (int r0 = level[l] + lane; r0 < end; r0 += 256) {
-      MtpRow8 rw[4];
-      double v[4];
+    for (int r0 = level[l] + lane; r0 < end; r0 += 64 * U) {
+      MtpRow8 rw[U];
+      double v[U];
 #pragma unroll
-      for (int u = 0; u < 4; u++) rw[u] = rows[min(r0 + 64 * u, end - 1)];   // clamped: no pointer select
+      for (int u = 0; u < U; u++) rw[u] = rows[min(r0 + 64 * u, end - 1)];   // clamped: no pointer select
 #pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = M[rw[u].lo & 0xffffu] * M[rw[u].lo >> 16];
+      for (int u = 0; u < U; u++) v[u] = M[rw[u].lo & 0xffffu] * M[rw[u].lo >> 16];
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+      for (int u = 0; u < U; u++)
         if (r0 + 64 * u < end) lds_add(&M[rw[u].hi & 0xffffu], (double) ((int) rw[u].hi >> 16) * v[u]);
     }
     wave_fence();
@@ -198,24 +230,25 @@ __device__ __forceinline__ void products_forward(const MtpRow8 *rows, const int 
 }
 
 // Phase 4b: D[a1] += D[a3] mult M[a0]; D[a0] += D[a3] mult M[a1], levels in reverse.
+template <int U>
 __device__ __forceinline__ void products_backward(const MtpRow8 *rows, const int *level, int nlevels,
                                                   const double *M, double *D, int lane)
 {
   for (int l = nlevels - 1; l >= 0; l--) {
     const int end = level[l + 1];
-    for (int r0 = level[l] + lane; r0 < end; r0 += 256) {
-      MtpRow8 rw[4];
-      double d3[4], m0[4], m1[4];
+    for (int r0 = level[l] + lane; r0 < end; r0 += 64 * U) {
+      MtpRow8 rw[U];
+      double d3[U], m0[U], m1[U];
 #pragma unroll
-      for (int u = 0; u < 4; u++) rw[u] = rows[min(r0 + 64 * u, end - 1)];
+      for (int u = 0; u < U; u++) rw[u] = rows[min(r0 + 64 * u, end - 1)];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < U; u++) {
         d3[u] = D[rw[u].hi & 0xffffu] * (double) ((int) rw[u].hi >> 16);
         m0[u] = M[rw[u].lo & 0xffffu];
         m1[u] = M[rw[u].lo >> 16];
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+      for (int u = 0; u < U; u++)
         if (r0 + 64 * u < end) {
           lds_add(&D[rw[u].lo >> 16], d3[u] * m0[u]);
           lds_add(&D[rw[u].lo & 0xffffu], d3[u] * m1[u]);
@@ -224,7 +257,6 @@ __device__ __forceinline__ void products_backward(const MtpRow8 *rows, const int
     wave_fence();
   }
 }
-
 
 // ---- phase 5 helpers ------------------------------------------------------------------------
 // sum_{i<C} coef[i] * m[i]; the coefficient address is the same in all lanes of a half (LDS broadcast)
@@ -381,40 +413,58 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     STAMP(0);   // loop head: ilist/type/x/first loads issue
     // ---- 1. compaction (the first NT survivors go straight into the tile arrays) --------
     int cnt = 0;
-    for (int c0 = 0; c0 < jnum; c0 += 64) {
-      const int jj = c0 + lane;
-      bool in = false;
-      int j = 0, jt = 0;
-      double dx = 0, dy = 0, dz = 0, r2 = 1.0;
-      if (jj < jnum) {
-        j = p.neigh[jbeg + jj] & MTP_NEIGHMASK;
-        jt = p.type[j] - 1;
-        if (jt < 0 || jt >= p.Sp) {   // pair_mtp.cpp:116-118
-          atomicExch(p.err_flag, 1);
-        } else {
-          dx = p.x[3 * (size_t) j] - xi0;
-          dy = p.x[3 * (size_t) j + 1] - xi1;
-          dz = p.x[3 * (size_t) j + 2] - xi2;
-          r2 = dx * dx + dy * dy + dz * dz;
-          in = !(r2 > p.cutsq);   // pair_mtp.cpp:123
-        }
+    for (int c0 = 0; c0 < jnum; c0 += 128) {
+      // two list entries per lane; the loads of both are in flight together (clamped indices, no branches)
+      int j2[2], jt2[2];
+      double d2[2][3];
+      bool ok2[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int jj = c0 + 64 * u + lane;
+        ok2[u] = jj < jnum;
+        j2[u] = p.neigh[jbeg + min(jj, jnum - 1)] & MTP_NEIGHMASK;
       }
-      const unsigned long long m = __ballot(in);
-      if (in) {
-        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-        w.cj[pos] = j;
-        if (pos < NT) {
-          const double r = sqrt(r2);
-          w.nbx[pos] = dx;
-          w.nby[pos] = dy;
-          w.nbz[pos] = dz;
-          w.nbr[pos] = r;
-          w.nbi[pos] = 1.0 / r;
-          w.nbj[pos] = j;
-          w.nbjt[pos] = jt;
-        }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        jt2[u] = p.type[j2[u]] - 1;
+        d2[u][0] = p.x[3 * (size_t) j2[u]];
+        d2[u][1] = p.x[3 * (size_t) j2[u] + 1];
+        d2[u][2] = p.x[3 * (size_t) j2[u] + 2];
       }
-      cnt += __builtin_amdgcn_readfirstlane(__popcll(m));
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (u == 1 && c0 + 64 >= jnum) break;   // uniform
+        const int j = j2[u], jt = jt2[u];
+        bool in = false;
+        double dx = 0, dy = 0, dz = 0, r2 = 1.0;
+        if (ok2[u]) {
+          if (jt < 0 || jt >= p.Sp) {   // pair_mtp.cpp:116-118
+            atomicExch(p.err_flag, 1);
+          } else {
+            dx = d2[u][0] - xi0;
+            dy = d2[u][1] - xi1;
+            dz = d2[u][2] - xi2;
+            r2 = dx * dx + dy * dy + dz * dz;
+            in = !(r2 > p.cutsq);   // pair_mtp.cpp:123
+          }
+        }
+        const unsigned long long m = __ballot(in);
+        if (in) {
+          const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+          w.cj[pos] = j;
+          if (pos < NT) {
+            const double r = sqrt(r2);
+            w.nbx[pos] = dx;
+            w.nby[pos] = dy;
+            w.nbz[pos] = dz;
+            w.nbr[pos] = r;
+            w.nbi[pos] = 1.0 / r;
+            w.nbj[pos] = j;
+            w.nbjt[pos] = jt;
+          }
+        }
+        cnt += __builtin_amdgcn_readfirstlane(__popcll(m));
+      }
     }
     {   // dummy neighbours pad tile 0 to a multiple of NG
       const int pos = cnt + lane;
@@ -438,7 +488,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     const int ntiles = (cnt + NT - 1) / NT;
     for (int tile = 0; tile < ntiles; tile++) {
       const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-      build_tile<PITCH>(p, bt, w, t0, cnt, ntp, tile > 0, xi0, xi1, xi2, i, itype, lane);
+      build_tile<PITCH>(p, bt, w, t0, cnt, ntp, tile > 0, true, xi0, xi1, xi2, i, itype, lane);
       STAMP(2);   // tile tables
 #pragma unroll
       for (int m = 0; m < NPG; m++) {
@@ -466,8 +516,8 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     // sum over the neighbour groups, then moments + adjoints into LDS
 #pragma unroll
     for (int t = 0; t < KB; t++) {
-      if (NG >= 2) acc[t] += shfl_xor_f64(acc[t], KL);
-      if (NG >= 4) acc[t] += shfl_xor_f64(acc[t], 2 * KL);
+      if (NG >= 4) acc[t] = pair_sum16(acc[t]);   // KL = 16: groups differ in lane bits 4 and 5
+      if (NG >= 2) acc[t] = pair_sum32(acc[t]);
     }
     for (int m = p.B + lane; m < p.A; m += 64) w.M[m] = 0.0;
     for (int m = lane; m < p.A; m += 64) w.D[m] = 0.0;
@@ -479,8 +529,8 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     wave_fence();
 
     // ---- 4a. products, level by level (pair_mtp.cpp:196-201) -----------------------------
-    if (rows_lds) products_forward(bt.rows, bt.level, p.nlevels, w.M, lane);
-    else products_forward(p.rows, bt.level, p.nlevels, w.M, lane);
+    if (rows_lds) products_forward<MTP_PU>(bt.rows, bt.level, p.nlevels, w.M, lane);
+    else products_forward<MTP_PU>(p.rows, bt.level, p.nlevels, w.M, lane);
     STAMP(4);   // products forward
     // ---- candidate vector, species and linear blocks (pair_mtp_extrapolation.cpp:235-252) ----
     if (GRADE) {
@@ -496,28 +546,39 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     for (int k = lane; k < p.nseed; k += 64) w.D[bt.seed_idx[k]] = bt.seed_val[k];
     wave_fence();
     STAMP(5);   // energy + seeds
-    if (rows_lds) products_backward(bt.rows, bt.level, p.nlevels, w.M, w.D, lane);
-    else products_backward(p.rows, bt.level, p.nlevels, w.M, w.D, lane);
+    if (rows_lds) products_backward<MTP_PU>(bt.rows, bt.level, p.nlevels, w.M, w.D, lane);
+    else products_backward<MTP_PU>(p.rows, bt.level, p.nlevels, w.M, w.D, lane);
 
     STAMP(6);   // products backward
     // ---- 5. forces ---------------------------------------------------------------------------
     // the (now free) moment region receives the coefficient blocks of the derivative polynomials:
     // basic k = (slot s; a, b, c) puts a D_k at the d/dx coefficient of x^(a-1) y^b z^c, b D_k and c D_k alike
-    for (int k = lane; k < p.coef_total; k += 64) w.M[k] = 0.0;   // monomials the potential does not list
-    wave_fence();
-    for (int k = lane; k < (GRADE ? KL * KB : p.B); k += 64) {
-      const bool ok = k < p.B;
-      const double d = ok ? w.D[k] : 0.0;
-      if (GRADE) p.dbasic[(size_t) ii * p.dpad + k] = d;   // read back by mtp_cvec_kernel
-      if (ok) {
-        const int pk = bt.pack[k];
-        const int a = (pk >> 8) & 15, b = (pk >> 12) & 15, c = (pk >> 16) & 15;
-        const int j = b + c, nu = a + j, C = (nu * (nu + 1)) >> 1;
-        double *blk = w.M + bt.coef[pk & 255];
-        if (nu == 0) blk[0] = d;
-        if (a > 0) blk[((j * (j + 1)) >> 1) + c] = d * (double) a;
-        if (b > 0) blk[C + (((j - 1) * j) >> 1) + c] = d * (double) b;
-        if (c > 0) blk[2 * C + (((j - 1) * j) >> 1) + c - 1] = d * (double) c;
+    if (!p.coef_dense) {   // monomials the potential does not list
+      for (int k = lane; k < p.coef_total; k += 64) w.M[k] = 0.0;
+      wave_fence();
+    }
+    {
+      constexpr int ROUNDS = (KL * KB + 63) / 64;
+      double dd[ROUNDS];
+      int2 tg[ROUNDS];
+#pragma unroll
+      for (int u = 0; u < ROUNDS; u++) {   // all reads first: one LDS round trip
+        const int k = lane + 64 * u, kc = min(k, p.B - 1);
+        dd[u] = w.D[kc];
+        tg[u] = reinterpret_cast<const int2 *>(bt.coef)[kc];
+      }
+#pragma unroll
+      for (int u = 0; u < ROUNDS; u++) {
+        const int k = lane + 64 * u;
+        const bool ok = k < p.B;
+        if (GRADE && k < KL * KB) p.dbasic[(size_t) ii * p.dpad + k] = ok ? dd[u] : 0.0;   // read back by mtp_cvec_kernel
+        if (ok) {
+          const unsigned t0 = (unsigned) tg[u].x, t1 = (unsigned) tg[u].y;
+          const unsigned tx = t0 & 0xffffu, ty = t0 >> 16, tz = t1 & 0xffffu;
+          if (tx != 0xffffu) w.M[tx] = dd[u] * (double) ((t1 >> 16) & 15u);
+          if (ty != 0xffffu) w.M[ty] = dd[u] * (double) ((t1 >> 20) & 15u);
+          if (tz != 0xffffu) w.M[tz] = dd[u] * (double) ((t1 >> 24) & 15u);
+        }
       }
     }
     wave_fence();
@@ -530,7 +591,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
       asm volatile("" : "+v"(pcol));
       for (int tile = 0; tile < ntiles; tile++) {
         const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-        if (ntiles > 1) build_tile<PITCH>(p, bt, w, t0, cnt, ntp, true, xi0, xi1, xi2, i, itype, lane);
+        if (ntiles > 1) build_tile<PITCH>(p, bt, w, t0, cnt, ntp, true, false, xi0, xi1, xi2, i, itype, lane);
         // columns past ntp hold stale (finite or not) data: their lanes are masked at the end
         const double x = w.nbx[n], y = w.nby[n], z = w.nbz[n], inv = w.nbi[n];
         double UA = 0.0, VA = 0.0, UB = 0.0, VB = 0.0, S0 = 0.0;
@@ -546,8 +607,8 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
         force_degree<1, DEG, PITCH>(p, pcol, w.m_addr, part, x, y, z, mono, UA, VA, UB, VB);
         // sum_s dg_s P_s = r . sum_s (dg_s / nu) grad P_s  (+ rank 0), shared by both halves
         double S = (part ? z : x) * VA + y * VB + (part ? 0.0 : S0);
-        S += shfl_xor_f64(S, 32);
-        UB += shfl_xor_f64(UB, 32);
+        S = pair_sum32(S);
+        UB = pair_sum32(UB);
         const double sr = S * inv;
         const bool valid = n < nt;
         const double Fa = valid ? fma(sr, part ? z : x, UA) : 0.0;   // half 0: F_x, half 1: F_z
@@ -580,14 +641,18 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
       Butterfly<16>::run(part16, lane);
       tot = part16[0];
     } else {
+      // the mirror partners flip the low lane bits too, so they go first (while every lane still holds
+      // all entries); the quad butterfly then leaves entry (lane & 3) summed over the row
       double part4[4] = {fi0, fi1, fi2, 0.0};
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        part4[u] += partner_f64<8>(part4[u]);
+        part4[u] += partner_f64<4>(part4[u]);
+      }
       Butterfly<4>::run(part4, lane);
       tot = part4[0];
-      tot += shfl_xor_f64(tot, 4);
-      tot += shfl_xor_f64(tot, 8);
     }
-    tot += shfl_xor_f64(tot, 16);
-    tot += shfl_xor_f64(tot, 32);
+    tot = pair_sum32(pair_sum16(tot));
     if (lane < 9) {
       if (lane < 3) {
         unsafeAtomicAdd(&p.f[3 * (size_t) i + lane], tot);   // pair_mtp.cpp:248-250

@@ -480,5 +480,41 @@ int mtp_potential::finalize(std::string &err)
     const int s = slot_of[(size_t) q[0] * P + (q[1] + q[2] + q[3])];
     basic_pack[i] = s | (q[1] << 8) | (q[2] << 12) | (q[3] << 16) | (q[0] << 20);
   }
+  // where each basic's adjoint goes in the derivative-polynomial coefficient blocks: basic (s; a, b, c)
+  // contributes a*D to the d/dx coefficient of x^(a-1) y^b z^c, b*D and c*D alike (monomials of degree
+  // nu-1 ordered a descending, then b descending: index j(j+1)/2 + c with j = b + c); rank 0: D itself
+  if (coef_total > 65534) {
+    err = "derivative-polynomial coefficient blocks above 65534 entries are not supported by this build";
+    return MTP_ERR_LIMIT;
+  }
+  basic_tgt.assign((size_t) 2 * B, 0);
+  {
+    std::vector<int> hits((size_t) coef_total, 0);
+    for (int i = 0; i < B; i++) {
+      const int32_t *q = &alpha_index_basic[4 * (size_t) i];
+      const int a = q[1], b = q[2], c = q[3], j = b + c, nu = a + j, C = nu * (nu + 1) / 2;
+      const int base = slot_coef_off[(size_t) (basic_pack[i] & 255)];
+      uint32_t tx = 0xffffu, ty = 0xffffu, tz = 0xffffu, fa = (uint32_t) a;
+      if (nu == 0) {
+        tx = (uint32_t) base;
+        fa = 1;
+      }
+      if (a > 0) tx = (uint32_t) (base + j * (j + 1) / 2 + c);
+      if (b > 0) ty = (uint32_t) (base + C + (j - 1) * j / 2 + c);
+      if (c > 0) tz = (uint32_t) (base + 2 * C + (j - 1) * j / 2 + c - 1);
+      for (uint32_t t : {tx, ty, tz})
+        if (t != 0xffffu) hits[t]++;
+      basic_tgt[2 * (size_t) i] = (int32_t) (tx | (ty << 16));
+      basic_tgt[2 * (size_t) i + 1] = (int32_t) (tz | (fa << 16) | ((uint32_t) b << 20) | ((uint32_t) c << 24));
+    }
+    coef_dense = 1;
+    for (int t = 0; t < coef_total; t++) {
+      if (hits[t] > 1) {
+        err = "alpha_index_basic lists the same (mu, a, b, c) twice";
+        return MTP_ERR_TABLE;
+      }
+      if (hits[t] == 0) coef_dense = 0;
+    }
+  }
   return MTP_OK;
 }

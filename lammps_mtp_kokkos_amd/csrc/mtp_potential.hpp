@@ -42,6 +42,10 @@ struct mtp_potential {
   std::vector<int32_t> slot_coef_off;
   int deg_first[14] = {0}, deg_coef[14] = {0};
   int coef_total = 0;
+  // per basic: {tx | ty << 16, tz | fa << 16 | fb << 20 | fc << 24}: coefficient entries (0xffff = none) that
+  // receive fa*D, fb*D, fc*D; coef_dense = every entry has a source (no zero fill needed)
+  std::vector<int32_t> basic_tgt;
+  int coef_dense = 0;
   // per basic: slot | a<<8 | b<<12 | c<<16 | mu<<20 (what a lane needs per k)
   std::vector<int32_t> basic_pack;
   // adjoint seeds: D[idx] = val (last mapping entry wins, pair_mtp.cpp:217-218)

@@ -3,7 +3,7 @@
 OUT=gpurun_out/${1:-sweep}
 mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
-for cfg in "16 2" "16 4" "16 8" "32 1" "32 2" "32 3" "32 6" "32 7" "8 2" "8 4"; do
+for cfg in "32 1" "32 2" "32 4" "32 8" "32 7" "32 6"; do
   set -- $cfg
   MTP_NT=$1 MTP_WPB=$2 timeout -k 10 200 python bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/b_$1_$2.json 2> $OUT/b_$1_$2.err
   python - <<PY
