@@ -213,17 +213,20 @@ __device__ __forceinline__ void products_forward(const MtpRow8 *rows, const int 
                                                  int lane)
 {
   for (int l = 0; l < nlevels; l++) {
-    const int end = level[l + 1];
-    for (int r0 = level[l] + lane; r0 < end; r0 += 64 * U) {
+    // levels are padded to whole 64-row blocks on the host (neutral rows): no bounds checks, no lane masks
+    const int beg = __builtin_amdgcn_readfirstlane(level[l]);
+    const int nit = (__builtin_amdgcn_readfirstlane(level[l + 1]) - beg) >> 6;
+    const MtpRow8 *rp = rows + beg + lane;
+    for (int it = 0; it < nit; it += U) {
       MtpRow8 rw[U];
       double v[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) rw[u] = rows[min(r0 + 64 * u, end - 1)];   // clamped: no pointer select
+      for (int u = 0; u < U; u++) rw[u] = rp[64 * min(it + u, nit - 1)];   // uniform clamp: the tail re-reads the last block
 #pragma unroll
       for (int u = 0; u < U; u++) v[u] = M[rw[u].lo & 0xffffu] * M[rw[u].lo >> 16];
 #pragma unroll
       for (int u = 0; u < U; u++)
-        if (r0 + 64 * u < end) lds_add(&M[rw[u].hi & 0xffffu], (double) ((int) rw[u].hi >> 16) * v[u]);
+        if (it + u < nit) lds_add(&M[rw[u].hi & 0xffffu], (double) ((int) rw[u].hi >> 16) * v[u]);   // uniform branch
     }
     wave_fence();
   }
@@ -235,12 +238,14 @@ __device__ __forceinline__ void products_backward(const MtpRow8 *rows, const int
                                                   const double *M, double *D, int lane)
 {
   for (int l = nlevels - 1; l >= 0; l--) {
-    const int end = level[l + 1];
-    for (int r0 = level[l] + lane; r0 < end; r0 += 64 * U) {
+    const int beg = __builtin_amdgcn_readfirstlane(level[l]);
+    const int nit = (__builtin_amdgcn_readfirstlane(level[l + 1]) - beg) >> 6;
+    const MtpRow8 *rp = rows + beg + lane;
+    for (int it = 0; it < nit; it += U) {
       MtpRow8 rw[U];
       double d3[U], m0[U], m1[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) rw[u] = rows[min(r0 + 64 * u, end - 1)];
+      for (int u = 0; u < U; u++) rw[u] = rp[64 * min(it + u, nit - 1)];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         d3[u] = D[rw[u].hi & 0xffffu] * (double) ((int) rw[u].hi >> 16);
@@ -249,7 +254,7 @@ __device__ __forceinline__ void products_backward(const MtpRow8 *rows, const int
       }
 #pragma unroll
       for (int u = 0; u < U; u++)
-        if (r0 + 64 * u < end) {
+        if (it + u < nit) {
           lds_add(&D[rw[u].lo >> 16], d3[u] * m0[u]);
           lds_add(&D[rw[u].lo & 0xffffu], d3[u] * m1[u]);
         }
@@ -616,8 +621,12 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
         const double Fx = part ? 0.0 : Fa, Fz = part ? Fa : 0.0;
         if (valid) {
           const size_t j = (size_t) w.nbj[n];
+#ifndef MTP_EXP_NOSCATTER   // timing experiment only (wrong results)
           unsafeAtomicAdd(&p.f[3 * j + (part ? 2 : 0)], -Fa);   // pair_mtp.cpp:252-254
           if (part == 0) unsafeAtomicAdd(&p.f[3 * j + 1], -Fy);
+#else
+          if (Fa + Fy == 12345.678) p.f[3 * j] = Fa;   // keeps the values live
+#endif
         }
         fi0 += Fx;
         fi1 += Fy;

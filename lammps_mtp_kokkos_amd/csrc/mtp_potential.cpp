@@ -429,6 +429,23 @@ int mtp_potential::finalize(std::string &err)
     }
     std::copy(out.begin(), out.end(), rows_by_level.begin() + b);
   }
+  // Pad every level to whole 64-row blocks with neutral rows (multiplicity 0, operands = target, a
+  // different moment in every lane): the product kernels then run without bounds checks or lane masks.
+  {
+    std::vector<MtpRow> padded;
+    std::vector<int32_t> off((size_t) nlev + 1, 0);
+    for (int l = 1; l <= nlev; l++) {
+      const int b = level_offset[l - 1], e = level_offset[l];
+      padded.insert(padded.end(), rows_by_level.begin() + b, rows_by_level.begin() + e);
+      while ((int) padded.size() % 64 != 0) {
+        const int t = ((int) padded.size() % 64) % A;
+        padded.push_back(MtpRow{t, t, 0, t});
+      }
+      off[l] = (int32_t) padded.size();
+    }
+    rows_by_level.swap(padded);
+    level_offset.swap(off);
+  }
   for (int i = 0; i < S; i++)
     if (alpha_moment_mapping[i] < 0 || alpha_moment_mapping[i] >= A) {
       err = "alpha_moment_mapping refers to a moment outside alpha_moments_count";
