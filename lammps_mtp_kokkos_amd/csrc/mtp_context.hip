@@ -329,6 +329,7 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     bb.off_lin = put(pot->linear_coeffs.data(), pot->linear_coeffs.size() * sizeof(double));
     bb.off_pack = put(pot->basic_pack.data(), pot->basic_pack.size() * sizeof(int32_t));
     bb.off_coef = put(pot->basic_tgt.data(), pot->basic_tgt.size() * sizeof(int32_t));
+    bb.off_smu = put(pot->slot_mu.data(), pot->slot_mu.size() * sizeof(int32_t));
     blob.resize((blob.size() + 15) / 16 * 16, 0);
     bb.blob_bytes = (int) blob.size();
     c->d_blob.upload(blob.data(), blob.size(), st);
@@ -567,7 +568,12 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
   p.wave_doubles = L.wave_doubles;
   p.cvec = grade_flag ? c->d_cvec.ptr : nullptr;
   p.cpad = c->cpad;
-  p.dbasic = grade_flag ? c->d_dbasic.ptr : nullptr;
+  // the force kernel writes the radial block of the candidate vectors itself for the common table shape; other
+  // shapes leave the adjoints of the basics in HBM for mtp_cvec_kernel
+  const bool fused = grade_flag && c->pot->radial_basis_size == 8 && c->pot->radial_func_count <= 4 &&
+      c->pot->species_count <= 2 && std::getenv("MTP_GRADE_UNFUSED") == nullptr;
+  p.grade_fused = fused ? 1 : 0;
+  p.dbasic = grade_flag && !fused ? c->d_dbasic.ptr : nullptr;
   p.dpad = c->dpad;
   try {
     if (c->timing) {
@@ -584,10 +590,12 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
     }
     if ((eflag & MTP_ENERGY_GLOBAL) || vflag) HIP_CHECK(mtp_launch_ev_finish(c->d_ev_slots.ptr, d_ev, st));
     if (grade_flag) {
-      MtpDevParams pc = p;   // radial block of the candidate vectors from the adjoints left in HBM
-      pc.wave_doubles = c->lp[1].wave_doubles;
-      pc.tab_rows = c->lp[1].tab_rows;
-      HIP_CHECK(mtp_launch_cvec_kernel(pc, c->lp[1].grid, c->lp[1].wpb, c->lp[1].lds_bytes, st));
+      if (!fused) {
+        MtpDevParams pc = p;   // radial block of the candidate vectors from the adjoints left in HBM
+        pc.wave_doubles = c->lp[1].wave_doubles;
+        pc.tab_rows = c->lp[1].tab_rows;
+        HIP_CHECK(mtp_launch_cvec_kernel(pc, c->lp[1].grid, c->lp[1].wpb, c->lp[1].lds_bytes, st));
+      }
       if (cfg)
         HIP_CHECK(mtp_launch_colsum_kernel(c->d_cvec.ptr, c->cpad, c->pot->coeff_count, c->inum, d_coeff_ders, st));
       else

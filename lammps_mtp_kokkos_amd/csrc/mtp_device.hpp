@@ -39,6 +39,7 @@ struct MtpDevParams {
   int off_map;             // int[S]
   int off_lin;             // double[S]
   int off_pack;            // int[B] slot | a<<8 | b<<12 | c<<16 | mu<<20
+  int off_smu;             // int[nslot] radial function index mu of each slot
   int off_coef;            // int2[B] scatter targets of each basic's adjoint: {tx | ty << 16, tz | fa << 16 | fb << 20 | fc << 24}
   int rows_in_lds;
   const MtpRow8 *rows;     // [T] by level, in HBM (always valid)
@@ -60,6 +61,7 @@ struct MtpDevParams {
   int *err_flag;
   unsigned long long *stamps;   // [16] diagnostic build only (MTP_STAMPS), else unused
   int eflag, vflag, grade_flag;
+  int grade_fused;         // grade calls: the force kernel also writes the radial block of cvec (R = 8, Mu <= 4, Sp <= 2)
   // launch geometry
   int NT;                  // neighbours per LDS tile: 32 or 16 (table row pitch = NT + 2 doubles)
   int tab_rows;            // table rows = 2*nslot + 3*P (candidate-vector kernel: 4*P + R)

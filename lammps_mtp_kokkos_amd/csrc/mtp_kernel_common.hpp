@@ -51,14 +51,31 @@ template <int CTRL> static __device__ __forceinline__ double dpp_f64(double v)
   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
   return __longlong_as_double((long long) (((unsigned long long) (unsigned) hi << 32) | (unsigned) lo));
 }
-// value of the lane that differs in bit log2(H) (and possibly lower bits); H >= 16 goes through ds_bpermute
-template <int H> static __device__ __forceinline__ double partner_f64(double v)
+// value of the lane that differs in bit log2(H) (and possibly lower bits).  H = 16 / 32 use gfx950's row / half
+// swaps (lane maps measured with scripts/probes/permlane_probe.hip): with both operands equal to v,
+// v_permlane16_swap leaves rows {0,0,2,2} of v in the first register and rows {1,1,3,3} in the second.
+template <int H> static __device__ __forceinline__ double partner_f64(double v, int lane = 0)
 {
   if constexpr (H == 1) return dpp_f64<0xB1>(v);        // quad_perm [1,0,3,2]
   else if constexpr (H == 2) return dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
   else if constexpr (H == 4) return dpp_f64<0x141>(v);  // row_half_mirror
   else if constexpr (H == 8) return dpp_f64<0x140>(v);  // row_mirror
-  else return shfl_xor_f64(v, H);
+  else {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned) b, hi = (unsigned) (b >> 32);
+    if constexpr (H == 16) {
+      const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+      const auto c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+      const unsigned rl = (lane & 16) ? a[0] : a[1], rh = (lane & 16) ? c[0] : c[1];
+      return __longlong_as_double((long long) (((unsigned long long) rh << 32) | rl));
+    } else {
+      static_assert(H == 32, "partner distance");
+      const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+      const auto c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+      const unsigned rl = (lane & 32) ? a[0] : a[1], rh = (lane & 32) ? c[0] : c[1];
+      return __longlong_as_double((long long) (((unsigned long long) rh << 32) | rl));
+    }
+  }
 }
 
 // v + (value of lane l^16) and v + (value of lane l^32) with gfx950's row / half swaps: with both operands equal
@@ -126,7 +143,7 @@ template <int N> struct Butterfly {
     for (int i = 0; i < H; i++) {
       const double keep = hi ? v[i + H] : v[i];
       const double send = hi ? v[i] : v[i + H];
-      v[i] = keep + partner_f64<H>(send);
+      v[i] = keep + partner_f64<H>(send, lane);
     }
     Butterfly<H>::run(v, lane);
   }
@@ -137,7 +154,7 @@ template <> struct Butterfly<1> {
 
 struct BlockTables {   // views into the workgroup-shared head of LDS
   const MtpRow8 *rows;
-  const int *level, *slot, *seed_idx, *map, *pack, *coef;
+  const int *level, *slot, *seed_idx, *map, *pack, *coef, *smu;
   const double *radial, *seed_val, *lin;
 };
 

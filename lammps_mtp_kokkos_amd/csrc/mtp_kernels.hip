@@ -289,10 +289,12 @@ template <int C> __device__ __forceinline__ double poly_eval(unsigned coef, cons
 // (a descending, then b descending): idx(a, b, c) = j (j + 1) / 2 + c with j = b + c.  A slot's coefficient
 // block is [d/dx | d/dy | d/dz], each over those monomials.  UA/VA collect sum_s g_s dP_s/dx (half 0) or
 // dP_s/dz (half 1) and the same with dg_s / nu; UB/VB the d/dy terms of the slots this half owns.
-template <int NU, int DEG, int PITCH>
+// GRADE (fused candidate vectors): W[mu] collects this lane's share of W_mu(n) = sum_{s in mu} P_s(r_n) / r_n^nu
+// (pair_mtp_extrapolation.cpp:193-198), again through P_s = (r . grad P_s) / nu; rw = r^-NU on entry.
+template <int NU, int DEG, int PITCH, bool GRADE>
 __device__ __forceinline__ void force_degree(const MtpDevParams &p, unsigned pcol, unsigned pcoef, int part, double x,
                                              double y, double z, double *m, double &UA, double &VA, double &UB,
-                                             double &VB)
+                                             double &VB, const int *smu, double inv, double rw, double *W)
 {
   if constexpr (NU <= DEG) {
     constexpr int C = NU * (NU + 1) / 2;   // monomials of degree NU-1
@@ -300,6 +302,7 @@ __device__ __forceinline__ void force_degree(const MtpDevParams &p, unsigned pco
       const int s0 = p.deg_first[NU], cnt = p.deg_first[NU + 1] - s0;
       const double inv_nu = 1.0 / NU;
       const unsigned dgo = 8u * (unsigned) (p.nslot * PITCH);
+      const double wa = GRADE ? (part ? z : x) * (rw * inv_nu) : 0.0, wb = GRADE ? y * (rw * inv_nu) : 0.0;
       {
         unsigned ca = pcoef + 8u * (unsigned) (p.deg_coef[NU] + part * 2 * C);
         unsigned cg = pcol + 8u * (unsigned) (s0 * PITCH);
@@ -308,6 +311,12 @@ __device__ __forceinline__ void force_degree(const MtpDevParams &p, unsigned pco
           const double G = poly_eval<C>(ca, m);
           UA = fma(g, G, UA);
           VA = fma(dg * inv_nu, G, VA);
+          if (GRADE) {
+            const int mu = smu[s0 + it];
+            const double val = G * wa;
+#pragma unroll
+            for (int v = 0; v < 4; v++) W[v] += mu == v ? val : 0.0;
+          }
           ca += 8u * 3 * C;
           cg += 8u * PITCH;
         }
@@ -323,6 +332,12 @@ __device__ __forceinline__ void force_degree(const MtpDevParams &p, unsigned pco
         const double g = ok ? g_raw : 0.0, dg = ok ? dg_raw : 0.0;
         UB = fma(g, G, UB);
         VB = fma(dg * inv_nu, G, VB);
+        if (GRADE) {
+          const int mu = ok ? smu[s0 + sc] : -1;
+          const double val = G * wb;
+#pragma unroll
+          for (int v = 0; v < 4; v++) W[v] += mu == v ? val : 0.0;
+        }
       }
       if constexpr (NU < DEG) {
         // raise the monomials to degree NU: the new a = 0 tail from the old one, then the head times x
@@ -332,7 +347,7 @@ __device__ __forceinline__ void force_degree(const MtpDevParams &p, unsigned pco
         m[C + NU] = z * m[T0 + NU - 1];
 #pragma unroll
         for (int i = 0; i < C; i++) m[i] *= x;
-        force_degree<NU + 1, DEG, PITCH>(p, pcol, pcoef, part, x, y, z, m, UA, VA, UB, VB);
+        force_degree<NU + 1, DEG, PITCH, GRADE>(p, pcol, pcoef, part, x, y, z, m, UA, VA, UB, VB, smu, inv, rw * inv, W);
       }
     }
   }
@@ -363,6 +378,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
   bt.lin = reinterpret_cast<const double *>(sh + p.off_lin);
   bt.pack = reinterpret_cast<const int *>(sh + p.off_pack);
   bt.coef = reinterpret_cast<const int *>(sh + p.off_coef);
+  bt.smu = reinterpret_cast<const int *>(sh + p.off_smu);
   const bool rows_lds = p.rows_in_lds != 0;
 
   const int lane = threadIdx.x & 63;
@@ -576,7 +592,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
       for (int u = 0; u < ROUNDS; u++) {
         const int k = lane + 64 * u;
         const bool ok = k < p.B;
-        if (GRADE && k < KL * KB) p.dbasic[(size_t) ii * p.dpad + k] = ok ? dd[u] : 0.0;   // read back by mtp_cvec_kernel
+        if (GRADE && p.dbasic && k < KL * KB) p.dbasic[(size_t) ii * p.dpad + k] = ok ? dd[u] : 0.0;   // read back by mtp_cvec_kernel
         if (ok) {
           const unsigned t0 = (unsigned) tg[u].x, t1 = (unsigned) tg[u].y;
           const unsigned tx = t0 & 0xffffu, ty = t0 >> 16, tz = t1 & 0xffffu;
@@ -594,22 +610,54 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
       const int n = lane & 31, part = lane >> 5;
       unsigned pcol = w.addr(w.tab + n);
       asm volatile("" : "+v"(pcol));
+      double crad = 0.0;
       for (int tile = 0; tile < ntiles; tile++) {
         const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
         if (ntiles > 1) build_tile<PITCH>(p, bt, w, t0, cnt, ntp, true, false, xi0, xi1, xi2, i, itype, lane);
         // columns past ntp hold stale (finite or not) data: their lanes are masked at the end
         const double x = w.nbx[n], y = w.nby[n], z = w.nbz[n], inv = w.nbi[n];
         double UA = 0.0, VA = 0.0, UB = 0.0, VB = 0.0, S0 = 0.0;
+        double Wm[4] = {0.0, 0.0, 0.0, 0.0};
+        const bool fused = GRADE && p.grade_fused;
         {   // rank 0: P_s = D_k, no gradient
           unsigned cg = pcol + 8u * (unsigned) (ns * PITCH);
           for (int sidx = 0; sidx < p.deg_first[1]; sidx++) {
-            S0 = fma(lds_ld(cg, 0), w.M[p.deg_coef[0] + sidx], S0);
+            const double dk = w.M[p.deg_coef[0] + sidx];
+            S0 = fma(lds_ld(cg, 0), dk, S0);
+            if (GRADE) {
+              const int mu = bt.smu[sidx];
+#pragma unroll
+              for (int v = 0; v < 4; v++) Wm[v] += (mu == v && part == 0) ? dk : 0.0;
+            }
             cg += 8u * PITCH;
           }
         }
         double mono[DEG * (DEG + 1) / 2];
         mono[0] = 1.0;
-        force_degree<1, DEG, PITCH>(p, pcol, w.m_addr, part, x, y, z, mono, UA, VA, UB, VB);
+        force_degree<1, DEG, PITCH, GRADE>(p, pcol, w.m_addr, part, x, y, z, mono, UA, VA, UB, VB, bt.smu, inv, inv, Wm);
+        if (fused) {
+          // c[jt][mu][ri] += sum_n [type_n = jt] Q_ri(r_n) W_mu(n)  (pair_mtp_extrapolation.cpp:193-198, 323-329):
+          // half h of the wavefront reduces the 32 (mu, ri) entries of jt = h over its 32 neighbour lanes
+          double qv[8];
+          {
+            const double r = w.nbr[n], d = r - p.rmax;
+            const double ksi = (2.0 * r - (p.rmin + p.rmax)) * p.inv_span;
+            qv[0] = p.scaling * (d * d);
+            qv[1] = p.scaling * (ksi * d * d);
+#pragma unroll
+            for (int ri = 2; ri < 8; ri++) qv[ri] = 2.0 * ksi * qv[ri - 1] - qv[ri - 2];
+          }
+          const bool mine = n < nt && w.nbjt[n] == part;
+          double ent[32];
+#pragma unroll
+          for (int v = 0; v < 4; v++) {
+            const double wt = pair_sum32(Wm[v]);   // every lane takes part in the exchange; masked afterwards
+#pragma unroll
+            for (int ri = 0; ri < 8; ri++) ent[8 * v + ri] = mine ? qv[ri] * wt : 0.0;
+          }
+          Butterfly<32>::run(ent, lane);
+          crad += ent[0];   // lane (h, e): entry e = mu R + ri of block jt = h
+        }
         // sum_s dg_s P_s = r . sum_s (dg_s / nu) grad P_s  (+ rank 0), shared by both halves
         double S = (part ? z : x) * VA + y * VB + (part ? 0.0 : S0);
         S = pair_sum32(S);
@@ -640,6 +688,13 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
           v5 -= (Fy * z + Fz * y) * 0.5;
         }
         if (ntiles > 1) wave_fence();
+      }
+      if (GRADE && p.grade_fused) {   // radial block of the row: block (itype, jt), zeros elsewhere
+        const int MuR = p.Mu * 8, SMR = p.Sp * MuR;
+        double *crow = p.cvec + (size_t) ii * p.cpad;
+        for (int e = lane; e < p.Sp * SMR; e += 64)
+          if (e / SMR != itype) crow[e] = 0.0;
+        if (part < p.Sp && n < MuR) crow[(itype * p.Sp + part) * MuR + n] = crad;
       }
     }
     STAMP(7);   // forces

@@ -475,6 +475,7 @@ int mtp_potential::finalize(std::string &err)
   }
   slot_count = 0;
   slot_coef_off.clear();
+  slot_mu.clear();
   coef_total = 0;
   for (int nu = 0; nu < 14; nu++) {
     deg_first[nu] = slot_count;
@@ -484,6 +485,7 @@ int mtp_potential::finalize(std::string &err)
       if (slot_of[(size_t) mu * P + nu] == -2) {
         slot_of[(size_t) mu * P + nu] = slot_count++;
         slot_coef_off.push_back(coef_total);
+        slot_mu.push_back(mu);
         coef_total += nu == 0 ? 1 : 3 * (nu * (nu + 1) / 2);
       }
   }

@@ -39,7 +39,7 @@ struct mtp_potential {
   // slots sorted by tensor rank nu (then mu): rank d owns slots [deg_first[d], deg_first[d+1]);
   // slot_coef_off[s] = first double of the slot's derivative-polynomial coefficient block,
   // deg_coef[d] = that of rank d's first slot, coef_total = doubles of all blocks
-  std::vector<int32_t> slot_coef_off;
+  std::vector<int32_t> slot_coef_off, slot_mu;
   int deg_first[14] = {0}, deg_coef[14] = {0};
   int coef_total = 0;
   // per basic: {tx | ty << 16, tz | fa << 16 | fb << 20 | fc << 24}: coefficient entries (0xffff = none) that

@@ -319,6 +319,19 @@ def test_configuration_mode_candidate_vector():
     assert abs(g - want["max_grade"]) <= 1e-9 * max(1.0, want["max_grade"])
 
 
+def test_grades_general_path_matches_fused_path(monkeypatch):
+    """Shapes outside the fused case (R != 8, Mu > 4, more than two species) leave the adjoints of the basics in
+    HBM for mtp_cvec_kernel; MTP_GRADE_UNFUSED forces that path for a shape both can run."""
+    s = _system((3, 3, 3))
+    path = os.path.join(POT, "W_L16_nbh.almtp")
+    monkeypatch.setenv("MTP_GRADE_UNFUSED", "1")
+    pot, got, want = _grade_compare(path, s)
+    _close(got["grades"][s.ilist], want["grades"][s.ilist], "grades (general path)", atol=1e-9, rtol=1e-9)
+    monkeypatch.delenv("MTP_GRADE_UNFUSED")
+    pot2, got2, _ = _grade_compare(path, s)
+    _close(got2["grades"][s.ilist], got["grades"][s.ilist], "fused vs general", atol=1e-9, rtol=1e-9)
+
+
 def test_grades_without_selection_state_is_an_error():
     s = _system((2, 2, 2))
     pot = capi.Potential(os.path.join(POT, "W_L8.mtp"))
