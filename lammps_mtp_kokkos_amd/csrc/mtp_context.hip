@@ -85,7 +85,7 @@ struct mtp_context {
     int wpb = 1, grid = 1, wave_doubles = 0, tab_rows = 0, g_doubles = 0, m_doubles = 0, ov_doubles = 0;
     size_t lds_bytes = 0;
   } lp[2];   // [0] force calls (wavefront per atom), [1] candidate-vector kernel of grade calls
-  DevBuf<double> d_cvec, d_ainv_pad, d_dbasic;
+  DevBuf<double> d_cvec, d_ainv_pad, d_ainv_tiled, d_dbasic;
   int cpad = 0, dpad = 0;
   // timing
   bool timing = false;
@@ -340,6 +340,15 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
       for (int r = 0; r < C; r++)
         std::memcpy(&pad[(size_t) r * c->cpad], &pot->inverse_active_set[(size_t) r * C], (size_t) C * sizeof(double));
       c->d_ainv_pad.upload(pad, st);
+      // the same matrix in MFMA operand order for the LDS-staged grade kernel: [tile][k-step][lane],
+      // lane (j = l & 15, k = l >> 4) <- Ainv[16 tile + j][4 kstep + k]
+      std::vector<double> tiled((size_t) c->cpad * c->cpad, 0.0);
+      const int ks_n = c->cpad / 4;
+      for (int t = 0; t < c->cpad / 16; t++)
+        for (int ks = 0; ks < ks_n; ks++)
+          for (int l = 0; l < 64; l++)
+            tiled[((size_t) t * ks_n + ks) * 64 + l] = pad[(size_t) (16 * t + (l & 15)) * c->cpad + 4 * ks + (l >> 4)];
+      c->d_ainv_tiled.upload(tiled, st);
       HIP_CHECK(hipStreamSynchronize(st));
     }
     c->d_ev_slots.reserve((size_t) MTP_EV_SLOTS * 8);
@@ -599,7 +608,7 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
       if (cfg)
         HIP_CHECK(mtp_launch_colsum_kernel(c->d_cvec.ptr, c->cpad, c->pot->coeff_count, c->inum, d_coeff_ders, st));
       else
-        HIP_CHECK(mtp_launch_grade_kernel(c->d_cvec.ptr, c->d_ainv_pad.ptr, c->cpad, c->pot->coeff_count, c->inum,
+        HIP_CHECK(mtp_launch_grade_kernel(c->d_cvec.ptr, c->d_ainv_pad.ptr, c->d_ainv_tiled.ptr, c->cpad, c->pot->coeff_count, c->inum,
                                           c->ilist, d_grades, d_max_grade, st));
     }
   } catch (const HipFail &f) {

@@ -79,8 +79,9 @@ hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size
 hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st);
 // radial block of cvec from dbasic (grade calls, after the force kernel)
 hipError_t mtp_launch_cvec_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);
-// grades[ilist[ii]] = max_r |sum_c cvec[ii][c] Ainv[r][c]| (f64 MFMA), running maximum into max_grade
-hipError_t mtp_launch_grade_kernel(const double *cvec, const double *ainv_pad, int cpad, int C, int inum,
-                                   const int *ilist, double *grades, double *max_grade, hipStream_t st);
+// grades[ilist[ii]] = max_r |sum_c cvec[ii][c] Ainv[r][c]| (f64 MFMA), running maximum into max_grade;
+// ainv_tiled = Ainv in MFMA operand order [cpad/16][cpad/4][64] (used when cpad <= 160), else ainv_pad [cpad][cpad]
+hipError_t mtp_launch_grade_kernel(const double *cvec, const double *ainv_pad, const double *ainv_tiled, int cpad,
+                                   int C, int inum, const int *ilist, double *grades, double *max_grade, hipStream_t st);
 // coeff_ders[c] += sum_ii cvec[ii][c]
 hipError_t mtp_launch_colsum_kernel(const double *cvec, int cpad, int C, int inum, double *coeff_ders, hipStream_t st);

@@ -821,6 +821,88 @@ __global__ void __launch_bounds__(256) mtp_grade_kernel(const double *__restrict
     atomicMax(reinterpret_cast<unsigned long long *>(max_grade), (unsigned long long) __double_as_longlong(wmax));
 }
 
+// The same contraction for cpad <= 160 with the inverse active set shared through LDS: a workgroup of 8 wavefronts
+// (128 atoms, their 16 x cpad blocks of cvec in registers) walks the 16-row tiles of Ainv together; each tile is
+// fetched from L2 once per workgroup into a double-buffered LDS stage, already in MFMA operand order (the host
+// stores Ainv as [tile][k-step][lane], lane (j = l&15, k = l>>4) holding Ainv[16 tile + j][4 kstep + k]), so a B
+// operand is one conflict-free 512-byte ds_read per MFMA.  L2 traffic drops from 205 KB per 16 atoms to per 128.
+template <int KS_REG>
+__global__ void __launch_bounds__(512) mtp_grade_kernel_lds(const double *__restrict__ cvec,
+                                                           const double *__restrict__ ainv_t, int cpad, int inum,
+                                                           const int *__restrict__ ilist, double *grades,
+                                                           double *max_grade)
+{
+  extern __shared__ double stage[];   // [2][cpad * 16]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int atom0 = (blockIdx.x * 8 + wave) * 16;
+  const bool live = atom0 < inum;     // idle wavefronts still take part in the staging and the barriers
+  const int li = lane & 15, lk = lane >> 4;
+  const int ksteps = cpad >> 2, ntile = cpad >> 4, tile_doubles = cpad * 16;
+  const int arow = min(atom0 + li, inum - 1);   // clamped: rows past the end are computed and dropped
+  const double *ap = cvec + (size_t) arow * cpad + lk;
+  double areg[KS_REG];
+#pragma unroll
+  for (int ks = 0; ks < KS_REG; ks++) areg[ks] = ks < ksteps ? ap[4 * ks] : 0.0;
+  constexpr int PF = (KS_REG * 64 + 511) / 512;   // doubles per thread per tile
+  double pf[PF];
+#pragma unroll
+  for (int u = 0; u < PF; u++) {
+    const int e = threadIdx.x + 512 * u;
+    if (e < tile_doubles) stage[e] = ainv_t[e];
+  }
+  __syncthreads();
+  double gmax[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int t = 0; t < ntile; t++) {
+    const double *cur = stage + (size_t) (t & 1) * tile_doubles;
+    double *nxt = stage + (size_t) ((t + 1) & 1) * tile_doubles;
+    if (t + 1 < ntile) {
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        const int e = threadIdx.x + 512 * u;
+        pf[u] = e < tile_doubles ? ainv_t[(size_t) (t + 1) * tile_doubles + e] : 0.0;
+      }
+    }
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KS_REG; ks++)
+      if (ks < ksteps) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[ks], cur[ks * 64 + lane], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) gmax[r] = fmax(gmax[r], fabs(acc[r]));
+    if (t + 1 < ntile) {
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        const int e = threadIdx.x + 512 * u;
+        if (e < tile_doubles) nxt[e] = pf[u];
+      }
+    }
+    __syncthreads();
+  }
+  // max over the 16 lanes (Ainv rows) that share l>>4
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    gmax[r] = fmax(gmax[r], partner_f64<1>(gmax[r]));
+    gmax[r] = fmax(gmax[r], partner_f64<2>(gmax[r]));
+    gmax[r] = fmax(gmax[r], partner_f64<4>(gmax[r]));
+    gmax[r] = fmax(gmax[r], partner_f64<8>(gmax[r]));
+  }
+  double wmax = 0.0;
+  if (live && li == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int a = atom0 + lk + 4 * r;   // D row = (l>>4) + 4*reg
+      if (a < inum) {
+        grades[ilist[a]] = gmax[r];   // pair_mtp_extrapolation.cpp:335
+        wmax = fmax(wmax, gmax[r]);
+      }
+    }
+  }
+  wmax = fmax(wmax, partner_f64<16>(wmax, lane));
+  wmax = fmax(wmax, partner_f64<32>(wmax, lane));
+  // grades are >= 0, so their IEEE bit patterns order like unsigned integers
+  if (live && lane == 0 && max_grade)
+    atomicMax(reinterpret_cast<unsigned long long *>(max_grade), (unsigned long long) __double_as_longlong(wmax));
+}
+
 // configuration mode: coeff_ders[c] += sum_i cvec[i][c]  (pair_mtp_extrapolation.cpp:97-98, 240-252, 327)
 __global__ void __launch_bounds__(256) mtp_colsum_kernel(const double *__restrict__ cvec, int cpad, int C, int inum,
                                                         double *coeff_ders)
@@ -912,17 +994,18 @@ hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size
   return hipErrorInvalidValue;
 }
 
-hipError_t mtp_launch_grade_kernel(const double *cvec, const double *ainv_pad, int cpad, int C, int inum,
-                                   const int *ilist, double *grades, double *max_grade, hipStream_t st)
+hipError_t mtp_launch_grade_kernel(const double *cvec, const double *ainv_pad, const double *ainv_tiled, int cpad,
+                                   int C, int inum, const int *ilist, double *grades, double *max_grade, hipStream_t st)
 {
   (void) C;
-  const int blocks = (inum + 63) / 64;
-  if (cpad <= 160)
-    hipLaunchKernelGGL(mtp_grade_kernel<40>, dim3(blocks), dim3(256), 0, st, cvec, ainv_pad, cpad, inum, ilist, grades,
-                       max_grade);
-  else
-    hipLaunchKernelGGL(mtp_grade_kernel<0>, dim3(blocks), dim3(256), 0, st, cvec, ainv_pad, cpad, inum, ilist, grades,
-                       max_grade);
+  if (cpad <= 160 && ainv_tiled) {
+    const size_t lds = (size_t) 2 * cpad * 16 * sizeof(double);
+    hipLaunchKernelGGL(mtp_grade_kernel_lds<40>, dim3((inum + 127) / 128), dim3(512), lds, st, cvec, ainv_tiled, cpad,
+                       inum, ilist, grades, max_grade);
+  } else {
+    hipLaunchKernelGGL(mtp_grade_kernel<0>, dim3((inum + 63) / 64), dim3(256), 0, st, cvec, ainv_pad, cpad, inum, ilist,
+                       grades, max_grade);
+  }
   return hipGetLastError();
 }
 
