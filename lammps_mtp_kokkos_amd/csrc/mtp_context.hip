@@ -127,19 +127,24 @@ void mtp_context::plan()
       if (blk > LDS) return 0;
       return std::min<int>(8, (int) (LDS / blk) * w);
     };
-    const int wmax = (variant == MTP_VARIANT_SMALL || (variant == MTP_VARIANT_AUTO && inum < num_cus * 16))
-        ? 2 : MTP_MAX_WPB;
+    // few atoms (or the "small" variant): the finest spread that still reaches the best occupancy;
+    // many atoms: as many wavefronts per workgroup as possible (fewer copies of the table blob)
+    const bool fine = variant == MTP_VARIANT_SMALL || (variant == MTP_VARIANT_AUTO && inum < num_cus * 16);
     int best_w = 0, best = 0;
-    for (int w = 1; w <= wmax; w++) {
+    for (int w = 1; w <= MTP_MAX_WPB; w++) {
       int v = waves_per_cu(w);
-      // prefer occupancy; at equal occupancy more waves per workgroup (fewer copies of the table blob)
-      if (v > best || (v == best && v > 0 && w > best_w)) {
+      if (v > best || (v == best && v > 0 && !fine)) {
         best = v;
         best_w = w;
       }
     }
     if (best == 0) throw HipFail{hipErrorInvalidValue, "potential + neighbour list exceed one CU's LDS"};
-    if (variant == MTP_VARIANT_SMALL) best_w = 1;   // finest spread of few atoms
+    if (fine)   // ... but no wider than needed to give every atom its own wavefront
+      for (int w = 1; w < best_w; w++)
+        if ((long long) num_cus * waves_per_cu(w) >= inum) {
+          best_w = w;
+          break;
+        }
     if (const char *e = std::getenv("MTP_WPB")) {   // tuning override (benchmarks only)
       int v = std::atoi(e);
       if (v >= 1 && v <= MTP_MAX_WPB && waves_per_cu(v) > 0) best_w = v;
@@ -632,6 +637,10 @@ int mtp_synchronize(mtp_context *c, void *stream)
   if (flag) {
     (void) hipMemsetAsync(c->d_err.ptr, 0, sizeof(int), st);
     (void) hipStreamSynchronize(st);
+    if (flag == 2) {
+      c->last_error = "a neighbour list row holds more in-cutoff neighbours than the declared max_numneigh";
+      return MTP_ERR_LIMIT;
+    }
     c->last_error = "Too few species count in the MTP potential!";   // pair_mtp.cpp:92-93
     return MTP_ERR_SPECIES;
   }

@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
         const unsigned long long m = __ballot(in);
         if (in) {
           const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-          w.cj[pos] = j;
+          if (pos < p.cj_cap) w.cj[pos] = j;   // a list longer than the declared max_numneigh is reported below
           if (pos < NT) {
             const double r = sqrt(r2);
             w.nbx[pos] = dx;
@@ -486,6 +486,10 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
         }
         cnt += __builtin_amdgcn_readfirstlane(__popcll(m));
       }
+    }
+    if (cnt > p.cj_cap) {   // the caller's max_numneigh sized the id array: refuse instead of overrunning LDS
+      if (lane == 0) atomicExch(p.err_flag, 2);
+      cnt = p.cj_cap;
     }
     {   // dummy neighbours pad tile 0 to a multiple of NG
       const int pos = cnt + lane;

@@ -229,6 +229,32 @@ def test_device_pointer_path_matches_host_path():
     _close(ea.cpu().numpy(), want["eatom"], "device eatom")
 
 
+def test_understated_max_numneigh_is_reported_not_overrun():
+    """mtp_set_neighbors_device sizes an LDS array from the caller's max_numneigh; a row with more in-cutoff
+    neighbours than that must end in MTP_ERR_LIMIT, not in an LDS overrun."""
+    import torch
+    s = _system((4, 4, 4), a=2.2, list_cutoff=6.0)      # ~100 neighbours inside the 5 A cutoff
+    pot = capi.Potential(os.path.join(POT, "W_L8.mtp"))
+    ctx = capi.Context(pot, 0)
+    dev = torch.device("cuda:0")
+    il, fi, ne = (torch.from_numpy(a).to(dev) for a in (s.ilist, s.first, s.neigh))
+    ctx.set_neighbors_device(il, fi, ne, s.nall, 8)      # declares 8: the id array holds 64
+    x = torch.from_numpy(s.x).to(dev)
+    ty = torch.from_numpy(s.types).to(dev)
+    f = torch.zeros((s.nall, 3), dtype=torch.float64, device=dev)
+    ctx.compute_device(x, ty, f, eflag=0, vflag=0)
+    with pytest.raises(capi.MtpError) as ei:
+        ctx.synchronize()
+    assert ei.value.code == -24
+    # the same list with an honest declaration works
+    ctx.set_neighbors_device(il, fi, ne, s.nall, int(np.diff(s.first).max()))
+    f.zero_()
+    ctx.compute_device(x, ty, f, eflag=0, vflag=0)
+    ctx.synchronize()
+    want = _oracle(os.path.join(POT, "W_L8.mtp")).compute(s.x, s.types, s.ilist, s.first, s.neigh)
+    _close(f.cpu().numpy(), want["f"], "forces after re-declaring")
+
+
 def test_golden_fixtures():
     gdir = os.path.join(ROOT, "tests", "golden")
     names = sorted(f for f in os.listdir(gdir) if f.endswith(".npz"))
