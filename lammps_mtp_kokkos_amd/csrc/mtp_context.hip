@@ -67,6 +67,8 @@ struct mtp_context {
   DevBuf<double> d_species;
   DevBuf<MtpRow8> d_rows;
   DevBuf<unsigned char> d_blob;
+  DevBuf<int32_t> d_seed_idx, d_map;
+  DevBuf<double> d_seed_val, d_lin;
   // neighbour list
   DevBuf<int> d_ilist, d_first, d_neigh;
   const int *ilist = nullptr, *first = nullptr, *neigh = nullptr;   // active (owned or caller's)
@@ -328,10 +330,25 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
         slot_pad[(size_t) mu * MTP_PSTRIDE + nu] = pot->slot_of[(size_t) mu * pot->max_alpha_index_basic + nu];
     bb.off_slot = put(slot_pad.data(), slot_pad.size() * sizeof(int32_t));
     bb.off_radial = put(pot->radial_basis_coeffs.data(), pot->radial_basis_coeffs.size() * sizeof(double));
-    bb.off_seed_idx = put(pot->seed_idx.data(), pot->seed_idx.size() * sizeof(int32_t));
-    bb.off_seed_val = put(pot->seed_val.data(), pot->seed_val.size() * sizeof(double));
-    bb.off_map = put(pot->alpha_moment_mapping.data(), pot->alpha_moment_mapping.size() * sizeof(int32_t));
-    bb.off_lin = put(pot->linear_coeffs.data(), pot->linear_coeffs.size() * sizeof(double));
+    // scalar-side tables (24 B per basis function): LDS when they are small, HBM/L2 otherwise
+    bb.scalars_in_lds = (pot->alpha_scalar_count + pot->seed_idx.size()) * 12 <= 4096;
+    if (const char *e = std::getenv("MTP_SCALARS_LDS")) bb.scalars_in_lds = std::atoi(e) != 0;   // tuning override
+    if (bb.scalars_in_lds) {
+      bb.off_seed_idx = put(pot->seed_idx.data(), pot->seed_idx.size() * sizeof(int32_t));
+      bb.off_seed_val = put(pot->seed_val.data(), pot->seed_val.size() * sizeof(double));
+      bb.off_map = put(pot->alpha_moment_mapping.data(), pot->alpha_moment_mapping.size() * sizeof(int32_t));
+      bb.off_lin = put(pot->linear_coeffs.data(), pot->linear_coeffs.size() * sizeof(double));
+    } else {
+      bb.off_seed_idx = bb.off_seed_val = bb.off_map = bb.off_lin = 0;
+    }
+    c->d_seed_idx.upload(pot->seed_idx, st);
+    c->d_seed_val.upload(pot->seed_val, st);
+    c->d_map.upload(pot->alpha_moment_mapping, st);
+    c->d_lin.upload(pot->linear_coeffs, st);
+    bb.g_seed_idx = c->d_seed_idx.ptr;
+    bb.g_seed_val = c->d_seed_val.ptr;
+    bb.g_map = c->d_map.ptr;
+    bb.g_lin = c->d_lin.ptr;
     bb.off_pack = put(pot->basic_pack.data(), pot->basic_pack.size() * sizeof(int32_t));
     bb.off_coef = put(pot->basic_tgt.data(), pot->basic_tgt.size() * sizeof(int32_t));
     bb.off_smu = put(pot->slot_mu.data(), pot->slot_mu.size() * sizeof(int32_t));

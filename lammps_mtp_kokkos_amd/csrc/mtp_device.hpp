@@ -42,6 +42,11 @@ struct MtpDevParams {
   int off_smu;             // int[nslot] radial function index mu of each slot
   int off_coef;            // int2[B] scatter targets of each basic's adjoint: {tx | ty << 16, tz | fa << 16 | fb << 20 | fc << 24}
   int rows_in_lds;
+  // scalar map / linear coefficients / adjoint seeds: in the blob when small, else read from HBM/L2 once per atom
+  // (at level 20 they are 11 KB, the difference between 3 and 4 wavefronts per CU)
+  int scalars_in_lds;
+  const int *g_map, *g_seed_idx;
+  const double *g_lin, *g_seed_val;
   const MtpRow8 *rows;     // [T] by level, in HBM (always valid)
   const double *species_coeffs;
   // system

@@ -561,14 +561,24 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     if (GRADE) {
       double *crow = p.cvec + (size_t) ii * p.cpad + p.Sp * p.Sp * p.Mu * p.R;
       for (int k = lane; k < p.Sp; k += 64) crow[k] = k == itype ? 1.0 : 0.0;
-      for (int k = lane; k < p.S; k += 64) crow[p.Sp + k] = w.M[bt.map[k]];
+      if (p.scalars_in_lds)
+        for (int k = lane; k < p.S; k += 64) crow[p.Sp + k] = w.M[bt.map[k]];
+      else
+        for (int k = lane; k < p.S; k += 64) crow[p.Sp + k] = w.M[p.g_map[k]];
     }
     // ---- site energy (pair_mtp.cpp:204-212) ----------------------------------------------
     double e = 0.0;
-    for (int k = lane; k < p.S; k += 64) e += bt.lin[k] * w.M[bt.map[k]];
+    // (two code paths per table home, LDS blob or HBM/L2: no pointer selects between address spaces, see below)
+    if (p.scalars_in_lds)
+      for (int k = lane; k < p.S; k += 64) e += bt.lin[k] * w.M[bt.map[k]];
+    else
+      for (int k = lane; k < p.S; k += 64) e += p.g_lin[k] * w.M[p.g_map[k]];
     e = wave_sum(e) + p.species_coeffs[itype];
     // ---- 4b. adjoints (pair_mtp.cpp:217-233) ----------------------------------------------
-    for (int k = lane; k < p.nseed; k += 64) w.D[bt.seed_idx[k]] = bt.seed_val[k];
+    if (p.scalars_in_lds)
+      for (int k = lane; k < p.nseed; k += 64) w.D[bt.seed_idx[k]] = bt.seed_val[k];
+    else
+      for (int k = lane; k < p.nseed; k += 64) w.D[p.g_seed_idx[k]] = p.g_seed_val[k];
     wave_fence();
     STAMP(5);   // energy + seeds
     if (rows_lds) products_backward<MTP_PU>(bt.rows, bt.level, p.nlevels, w.M, w.D, lane);
