@@ -104,6 +104,21 @@ int mtp_set_neighbors_csr(mtp_context *ctx, int inum, const int *ilist, const in
 /* CSR arrays already resident in HBM (no copy; must stay valid until replaced). */
 int mtp_set_neighbors_device(mtp_context *ctx, int inum, const int *d_ilist, const int *d_first,
                              const int *d_neigh, int nall, int max_numneigh);
+/* Builds that list on the GPU from positions resident in HBM (what LAMMPS' Neighbor class
+ * does ahead of the pair style, REQ_FULL at pair_mtp.cpp:317-318): a full list for atoms [0, inum) over all
+ * nall atoms (owned first, then explicit ghosts -- no periodic images are invented), entries j != i with
+ * |x_j - x_i|^2 <= list_cutoff^2.  lo / hi bound the positions of all nall atoms.  The list stays in the
+ * context (ilist = 0..inum-1) and is installed as by mtp_set_neighbors_device; d_first_out / d_neigh_out (may be
+ * null) receive device pointers to the CSR arrays, total_out / max_numneigh_out their sizes.  Synchronises the
+ * stream once (to size the entry array). */
+int mtp_build_neighbors_device(mtp_context *ctx, void *stream, const double *d_x, int inum, int nall,
+                               double list_cutoff, const double lo[3], const double hi[3],
+                               const int **d_first_out, const int **d_neigh_out, long long *total_out,
+                               int *max_numneigh_out);
+/* Copies the CSR arrays of the list the context owns (uploaded by mtp_set_neighbors[_csr] or built by
+ * mtp_build_neighbors_device) back to the host: first[inum + 1], neigh[first[inum]].  MTP_ERR_STATE when the
+ * current list lives in caller memory (mtp_set_neighbors_device). */
+int mtp_copy_neighbors_to_host(mtp_context *ctx, int *first, int *neigh);
 
 /* PairMTP::compute (pair_mtp.cpp:72-280) and, with grade_flag != 0,
  * PairMTPExtrapolation::compute (pair_mtp_extrapolation.cpp:68-382), on host arrays laid

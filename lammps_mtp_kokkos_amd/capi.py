@@ -23,7 +23,8 @@ EXPORTS = [
     "mtp_context_create", "mtp_context_destroy", "mtp_last_error", "mtp_context_set_variant",
     "mtp_set_neighbors", "mtp_set_neighbors_csr", "mtp_set_neighbors_device", "mtp_compute",
     "mtp_compute_device", "mtp_synchronize", "mtp_cfg_grade", "mtp_context_launch_info",
-    "mtp_context_set_timing", "mtp_context_last_kernel_ms",
+    "mtp_context_set_timing", "mtp_context_last_kernel_ms", "mtp_build_neighbors_device",
+    "mtp_copy_neighbors_to_host",
 ]
 
 
@@ -195,6 +196,28 @@ class Context:
         if grade:
             out.update(grades=grades, max_grade=mg.value, coeff_ders=cd)
         return out
+
+    def build_neighbors_device(self, x_t, inum, nall, list_cutoff, lo, hi, stream=None):
+        """Full neighbour list built on the GPU from device-resident positions; returns
+        (entries, longest row).  The list stays in the context."""
+        lo3 = (C.c_double * 3)(*[float(v) for v in lo])
+        hi3 = (C.c_double * 3)(*[float(v) for v in hi])
+        total, mx = C.c_longlong(0), C.c_int32(0)
+        st = C.c_void_p(stream) if stream else None
+        self._check(lib().mtp_build_neighbors_device(self.h, st, _ptr(x_t), int(inum), int(nall), C.c_double(list_cutoff),
+                                                     lo3, hi3, None, None, C.byref(total), C.byref(mx)))
+        self._inum = int(inum)
+        self.nall = int(nall)
+        return total.value, mx.value
+
+    def neighbors_to_host(self, inum=None, total=None):
+        """(first, neigh) of the list the context owns, as numpy arrays."""
+        inum = self._inum if inum is None else inum
+        first = np.zeros(inum + 1, dtype=np.int32)
+        self._check(lib().mtp_copy_neighbors_to_host(self.h, _np(first, C.c_int32), None))
+        neigh = np.zeros(max(int(first[-1]), 1), dtype=np.int32)
+        self._check(lib().mtp_copy_neighbors_to_host(self.h, _np(first, C.c_int32), _np(neigh, C.c_int32)))
+        return first, neigh[: int(first[-1])]
 
     def compute_device(self, x_t, type_t, f_t, eflag=0, vflag=0, grade=False, eatom_t=None, vatom_t=None,
                        ev_t=None, grades_t=None, maxg_t=None, coeff_t=None, stream=None):

@@ -71,6 +71,9 @@ struct mtp_context {
   DevBuf<double> d_seed_val, d_lin;
   // neighbour list
   DevBuf<int> d_ilist, d_first, d_neigh;
+  DevBuf<int> d_nb_scratch, d_nb_info;   // device neighbour-list build
+  hipStream_t list_stream = nullptr;     // stream the context-owned list was last written on
+  DevBuf<unsigned char> d_nb_tmp;
   const int *ilist = nullptr, *first = nullptr, *neigh = nullptr;   // active (owned or caller's)
   int inum = 0, nall = 0, max_numneigh = 0;
   bool have_list = false;
@@ -540,6 +543,82 @@ int mtp_set_neighbors_device(mtp_context *c, int inum, const int *d_ilist, const
   c->first = d_first;
   c->neigh = d_neigh;
   return finish_list(c, inum, nall, max_numneigh);
+}
+
+int mtp_build_neighbors_device(mtp_context *c, void *stream, const double *d_x, int inum, int nall,
+                               double list_cutoff, const double lo[3], const double hi[3],
+                               const int **d_first_out, const int **d_neigh_out, long long *total_out,
+                               int *max_numneigh_out)
+{
+  if (!c || inum < 0 || nall < inum || !lo || !hi || !(list_cutoff > 0.0) || (nall > 0 && !d_x)) return MTP_ERR_ARG;
+  if (hipSetDevice(c->device) != hipSuccess) {
+    c->last_error = "hipSetDevice failed";
+    return MTP_ERR_DEVICE;
+  }
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+  int n3[3];
+  long long ncell = 1;
+  for (int a = 0; a < 3; a++) {
+    if (!(hi[a] >= lo[a])) return MTP_ERR_ARG;
+    n3[a] = std::max(1, (int) std::ceil((hi[a] - lo[a]) / list_cutoff));
+    ncell *= n3[a];
+  }
+  if (ncell > (1ll << 26)) {
+    c->last_error = "neighbour build: more than 2^26 cells (box much larger than the atoms it holds?)";
+    return MTP_ERR_LIMIT;
+  }
+  try {
+    const size_t scan_n = (size_t) std::max<long long>(ncell, inum) + 1;
+    const size_t cub_bytes = mtp_neighbor_scan_bytes((int) scan_n);
+    c->d_nb_tmp.reserve(std::max<size_t>(cub_bytes, 16));
+    c->d_nb_scratch.reserve((size_t) 2 * nall + 3 * (size_t) ncell + 2 + (size_t) inum + 1);
+    c->d_nb_info.reserve(2);
+    c->d_ilist.reserve((size_t) std::max(inum, 1));
+    c->d_first.reserve((size_t) inum + 1);
+    HIP_CHECK(mtp_launch_neighbor_build(d_x, inum, nall, list_cutoff, lo, n3, c->d_nb_scratch.ptr, c->d_nb_tmp.ptr,
+                                        c->d_nb_tmp.cap, c->d_ilist.ptr, c->d_first.ptr, nullptr, c->d_nb_info.ptr, st));
+    int info[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(info, c->d_nb_info.ptr, sizeof(info), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (info[0] < 0 || (long long) inum * info[1] > 0x7fffffffll) {
+      c->last_error = "neighbour list has more than 2^31-1 entries on this rank";
+      return MTP_ERR_LIMIT;
+    }
+    c->d_neigh.reserve((size_t) std::max(info[0], 1));
+    HIP_CHECK(mtp_launch_neighbor_build(d_x, inum, nall, list_cutoff, lo, n3, c->d_nb_scratch.ptr, c->d_nb_tmp.ptr,
+                                        c->d_nb_tmp.cap, c->d_ilist.ptr, c->d_first.ptr, c->d_neigh.ptr,
+                                        c->d_nb_info.ptr, st));
+    c->ilist = c->d_ilist.ptr;
+    c->first = c->d_first.ptr;
+    c->neigh = c->d_neigh.ptr;
+    c->list_stream = st;
+    if (d_first_out) *d_first_out = c->d_first.ptr;
+    if (d_neigh_out) *d_neigh_out = c->d_neigh.ptr;
+    if (total_out) *total_out = info[0];
+    if (max_numneigh_out) *max_numneigh_out = info[1];
+    return finish_list(c, inum, nall, info[1]);
+  } catch (const HipFail &f) {
+    c->last_error = std::string(f.what) + ": " + hipGetErrorString(f.e);
+    return MTP_ERR_DEVICE;
+  }
+}
+
+int mtp_copy_neighbors_to_host(mtp_context *c, int *first, int *neigh)
+{
+  if (!c || !first) return MTP_ERR_ARG;
+  if (!c->have_list || c->first != c->d_first.ptr || c->neigh != c->d_neigh.ptr) {
+    if (c) c->last_error = "the current neighbour list is not owned by the context";
+    return MTP_ERR_STATE;
+  }
+  (void) hipSetDevice(c->device);
+  // the list was written on list_stream (a non-blocking stream: the copies below do not wait for it by themselves)
+  if (hipStreamSynchronize(c->list_stream ? c->list_stream : c->stream) != hipSuccess) return MTP_ERR_DEVICE;
+  if (hipMemcpy(first, c->d_first.ptr, sizeof(int) * ((size_t) c->inum + 1), hipMemcpyDeviceToHost) != hipSuccess)
+    return MTP_ERR_DEVICE;
+  if (neigh && first[c->inum] > 0 &&
+      hipMemcpy(neigh, c->d_neigh.ptr, sizeof(int) * (size_t) first[c->inum], hipMemcpyDeviceToHost) != hipSuccess)
+    return MTP_ERR_DEVICE;
+  return MTP_OK;
 }
 
 int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const int *d_type, int eflag, int vflag,

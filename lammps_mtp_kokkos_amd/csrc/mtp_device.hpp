@@ -90,3 +90,9 @@ hipError_t mtp_launch_grade_kernel(const double *cvec, const double *ainv_pad, c
                                    int C, int inum, const int *ilist, double *grades, double *max_grade, hipStream_t st);
 // coeff_ders[c] += sum_ii cvec[ii][c]
 hipError_t mtp_launch_colsum_kernel(const double *cvec, int cpad, int C, int inum, double *coeff_ders, hipStream_t st);
+// device neighbour-list build (mtp_neighbor_kernels.hip): stage 1 (neigh == nullptr) bins, counts and scans and
+// leaves {entries, longest row} in d_info[2]; stage 2 fills neigh[]
+hipError_t mtp_launch_neighbor_build(const double *x, int inum, int nall, double cutoff, const double lo[3],
+                                     const int ncell3[3], int *scratch, void *cub_tmp, size_t cub_bytes, int *ilist,
+                                     int *first, int *neigh, int *d_info, hipStream_t st);
+size_t mtp_neighbor_scan_bytes(int n);

@@ -255,6 +255,61 @@ def test_understated_max_numneigh_is_reported_not_overrun():
     _close(f.cpu().numpy(), want["f"], "forces after re-declaring")
 
 
+def _rows_as_sets(first, neigh):
+    return [np.sort(neigh[first[i]:first[i + 1]]) for i in range(len(first) - 1)]
+
+
+@pytest.mark.parametrize("ncell,a,cut", [((4, 4, 4), 3.165, 7.0), ((3, 4, 5), 2.9, 5.5), ((2, 2, 2), 3.165, 7.0)])
+def test_device_neighbour_build_matches_host_list(ncell, a, cut):
+    """the GPU-built full list holds, row by row, exactly the atoms of the host KD-tree list
+    (integer work: compared as sets, bit-exact), and forces computed from it match the oracle."""
+    import torch
+    s = _system(ncell, a=a, list_cutoff=cut)
+    path = os.path.join(POT, "W_L8.mtp")
+    pot = capi.Potential(path)
+    ctx = capi.Context(pot, 0)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(s.x).to(dev)
+    lo, hi = s.x.min(0) - 1e-9, s.x.max(0) + 1e-9
+    total, mx = ctx.build_neighbors_device(x, s.nlocal, s.nall, cut, lo, hi)
+    first, neigh = ctx.neighbors_to_host()
+    assert total == s.first[-1] and mx == np.diff(s.first).max()
+    assert np.array_equal(first, s.first)
+    for got, want in zip(_rows_as_sets(first, neigh), _rows_as_sets(s.first, s.neigh)):
+        assert np.array_equal(got, want)
+    ty = torch.from_numpy(s.types).to(dev)
+    f = torch.zeros((s.nall, 3), dtype=torch.float64, device=dev)
+    ctx.compute_device(x, ty, f, eflag=0, vflag=0)
+    ctx.synchronize()
+    want = _oracle(path).compute(s.x, s.types, s.ilist, s.first, s.neigh)
+    _close(f.cpu().numpy(), want["f"], "forces from the device-built list")
+    # rebuilding after the atoms moved gives the list of the new positions
+    rng = np.random.default_rng(11)
+    x2 = s.x + rng.normal(0, 0.2, s.x.shape)
+    from lammps_mtp_kokkos_amd.driver import full_neighbor_list
+    f2, n2 = full_neighbor_list(x2, s.nlocal, cut)
+    xt2 = torch.from_numpy(x2).to(dev)
+    ctx.build_neighbors_device(xt2, s.nlocal, s.nall, cut, x2.min(0), x2.max(0))
+    first2, neigh2 = ctx.neighbors_to_host()
+    assert np.array_equal(first2, f2)
+    for got, want in zip(_rows_as_sets(first2, neigh2), _rows_as_sets(f2, n2)):
+        assert np.array_equal(got, want)
+
+
+def test_device_neighbour_build_empty_and_single():
+    import torch
+    pot = capi.Potential(os.path.join(POT, "W_L8.mtp"))
+    ctx = capi.Context(pot, 0)
+    dev = torch.device("cuda:0")
+    x = torch.zeros((1, 3), dtype=torch.float64, device=dev)
+    total, mx = ctx.build_neighbors_device(x, 1, 1, 5.0, [0, 0, 0], [0, 0, 0])
+    assert (total, mx) == (0, 0)
+    first, neigh = ctx.neighbors_to_host()
+    assert first.tolist() == [0, 0] and len(neigh) == 0
+    total, mx = ctx.build_neighbors_device(x, 0, 1, 5.0, [0, 0, 0], [0, 0, 0])   # ghosts only
+    assert (total, mx) == (0, 0)
+
+
 def test_golden_fixtures():
     gdir = os.path.join(ROOT, "tests", "golden")
     names = sorted(f for f in os.listdir(gdir) if f.endswith(".npz"))
