@@ -74,6 +74,7 @@ struct mtp_context {
   DevBuf<int> d_nb_scratch, d_nb_info;   // device neighbour-list build
   hipStream_t list_stream = nullptr;     // stream the context-owned list was last written on
   DevBuf<unsigned char> d_nb_tmp;
+  DevBuf<double> d_nb_xs;
   const int *ilist = nullptr, *first = nullptr, *neigh = nullptr;   // active (owned or caller's)
   int inum = 0, nall = 0, max_numneigh = 0;
   bool have_list = false;
@@ -573,10 +574,12 @@ int mtp_build_neighbors_device(mtp_context *c, void *stream, const double *d_x, 
     c->d_nb_tmp.reserve(std::max<size_t>(cub_bytes, 16));
     c->d_nb_scratch.reserve((size_t) 2 * nall + 3 * (size_t) ncell + 2 + (size_t) inum + 1);
     c->d_nb_info.reserve(2);
+    c->d_nb_xs.reserve((size_t) 3 * std::max(nall, 1));
     c->d_ilist.reserve((size_t) std::max(inum, 1));
     c->d_first.reserve((size_t) inum + 1);
-    HIP_CHECK(mtp_launch_neighbor_build(d_x, inum, nall, list_cutoff, lo, n3, c->d_nb_scratch.ptr, c->d_nb_tmp.ptr,
-                                        c->d_nb_tmp.cap, c->d_ilist.ptr, c->d_first.ptr, nullptr, c->d_nb_info.ptr, st));
+    HIP_CHECK(mtp_launch_neighbor_build(d_x, inum, nall, list_cutoff, lo, n3, c->d_nb_scratch.ptr, c->d_nb_xs.ptr,
+                                        c->d_nb_tmp.ptr, c->d_nb_tmp.cap, c->d_ilist.ptr, c->d_first.ptr, nullptr,
+                                        c->d_nb_info.ptr, st));
     int info[2] = {0, 0};
     HIP_CHECK(hipMemcpyAsync(info, c->d_nb_info.ptr, sizeof(info), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
@@ -585,8 +588,8 @@ int mtp_build_neighbors_device(mtp_context *c, void *stream, const double *d_x, 
       return MTP_ERR_LIMIT;
     }
     c->d_neigh.reserve((size_t) std::max(info[0], 1));
-    HIP_CHECK(mtp_launch_neighbor_build(d_x, inum, nall, list_cutoff, lo, n3, c->d_nb_scratch.ptr, c->d_nb_tmp.ptr,
-                                        c->d_nb_tmp.cap, c->d_ilist.ptr, c->d_first.ptr, c->d_neigh.ptr,
+    HIP_CHECK(mtp_launch_neighbor_build(d_x, inum, nall, list_cutoff, lo, n3, c->d_nb_scratch.ptr, c->d_nb_xs.ptr,
+                                        c->d_nb_tmp.ptr, c->d_nb_tmp.cap, c->d_ilist.ptr, c->d_first.ptr, c->d_neigh.ptr,
                                         c->d_nb_info.ptr, st));
     c->ilist = c->d_ilist.ptr;
     c->first = c->d_first.ptr;

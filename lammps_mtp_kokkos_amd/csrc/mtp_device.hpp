@@ -93,6 +93,6 @@ hipError_t mtp_launch_colsum_kernel(const double *cvec, int cpad, int C, int inu
 // device neighbour-list build (mtp_neighbor_kernels.hip): stage 1 (neigh == nullptr) bins, counts and scans and
 // leaves {entries, longest row} in d_info[2]; stage 2 fills neigh[]
 hipError_t mtp_launch_neighbor_build(const double *x, int inum, int nall, double cutoff, const double lo[3],
-                                     const int ncell3[3], int *scratch, void *cub_tmp, size_t cub_bytes, int *ilist,
+                                     const int ncell3[3], int *scratch, double *xs, void *cub_tmp, size_t cub_bytes, int *ilist,
                                      int *first, int *neigh, int *d_info, hipStream_t st);
 size_t mtp_neighbor_scan_bytes(int n);

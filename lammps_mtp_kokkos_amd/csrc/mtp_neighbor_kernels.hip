@@ -72,17 +72,33 @@ __global__ void nb_sort_cells(const int *__restrict__ cell_start, int ncell, int
   }
 }
 
+// positions in cell order: the candidate loop of nb_walk then reads contiguous memory
+__global__ void nb_gather(const double *__restrict__ x, const int *__restrict__ cell_atoms, int nall,
+                          double *__restrict__ xs)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nall) return;
+  const int j = cell_atoms[k];
+  xs[3 * (size_t) k] = x[3 * (size_t) j];
+  xs[3 * (size_t) k + 1] = x[3 * (size_t) j + 1];
+  xs[3 * (size_t) k + 2] = x[3 * (size_t) j + 2];
+}
+
 template <bool FILL>
 __global__ void nb_walk(CellGrid g, const double *__restrict__ x, int inum, double cutsq,
                         const int *__restrict__ cell_start, const int *__restrict__ cell_atoms,
-                        int *__restrict__ numneigh, const int *__restrict__ first, int *__restrict__ neigh,
-                        int *__restrict__ max_numneigh)
+                        const double *__restrict__ xs, int nall, int *__restrict__ numneigh,
+                        const int *__restrict__ first, int *__restrict__ neigh, int *__restrict__ max_numneigh)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // threads in cell order: the lanes of a wavefront sit in the same or adjacent cells and walk the same
+  // candidates (their loads hit the same cache lines); ghosts have no row
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nall) return;
+  const int i = cell_atoms[t];
   if (i >= inum) return;
   int c[3];
   cell_of(g, x, i, c);
-  const double xi = x[3 * (size_t) i], yi = x[3 * (size_t) i + 1], zi = x[3 * (size_t) i + 2];
+  const double xi = xs[3 * (size_t) t], yi = xs[3 * (size_t) t + 1], zi = xs[3 * (size_t) t + 2];
   int cnt = 0;
   int *row = FILL ? neigh + first[i] : nullptr;
   for (int a = max(c[0] - 1, 0); a <= min(c[0] + 1, g.n[0] - 1); a++)
@@ -90,11 +106,10 @@ __global__ void nb_walk(CellGrid g, const double *__restrict__ x, int inum, doub
       for (int d = max(c[2] - 1, 0); d <= min(c[2] + 1, g.n[2] - 1); d++) {
         const int id = (a * g.n[1] + b) * g.n[2] + d;
         for (int k = cell_start[id]; k < cell_start[id + 1]; k++) {
-          const int j = cell_atoms[k];
-          if (j == i) continue;
-          const double dx = x[3 * (size_t) j] - xi, dy = x[3 * (size_t) j + 1] - yi, dz = x[3 * (size_t) j + 2] - zi;
+          if (k == t) continue;
+          const double dx = xs[3 * (size_t) k] - xi, dy = xs[3 * (size_t) k + 1] - yi, dz = xs[3 * (size_t) k + 2] - zi;
           if (dx * dx + dy * dy + dz * dz <= cutsq) {
-            if (FILL) row[cnt] = j;
+            if (FILL) row[cnt] = cell_atoms[k];
             cnt++;
           }
         }
@@ -116,9 +131,10 @@ __global__ void nb_iota(int *v, int n)
 // Builds the list into caller-provided device buffers in two calls around one host read of the entry count:
 //   stage 1 (neigh == nullptr): bins, counts, row offsets; writes {total entries, max row length} to d_info[2]
 //   stage 2 (neigh != nullptr): fills neigh[] (first[] must be the stage-1 result)
-// scratch ints: cell_id[nall] | cell_atoms[nall] | cell_start[ncell + 1] | cell_count[ncell + 1] | cursor[ncell] | numneigh[inum + 1]
+// scratch ints: cell_id[nall] | cell_atoms[nall] | cell_start[ncell + 1] | cell_count[ncell + 1] | cursor[ncell] | numneigh[inum + 1];
+// xs: 3 * nall doubles (positions in cell order)
 hipError_t mtp_launch_neighbor_build(const double *x, int inum, int nall, double cutoff, const double lo[3],
-                                     const int ncell3[3], int *scratch, void *cub_tmp, size_t cub_bytes, int *ilist,
+                                     const int ncell3[3], int *scratch, double *xs, void *cub_tmp, size_t cub_bytes, int *ilist,
                                      int *first, int *neigh, int *d_info, hipStream_t st)
 {
   CellGrid g;
@@ -141,18 +157,19 @@ hipError_t mtp_launch_neighbor_build(const double *x, int inum, int nall, double
     if (nall > 0) {
       hipLaunchKernelGGL(nb_place, dim3((nall + T - 1) / T), dim3(T), 0, st, cell_id, nall, cell_start, cursor, cell_atoms);
       hipLaunchKernelGGL(nb_sort_cells, dim3((ncell + T - 1) / T), dim3(T), 0, st, cell_start, ncell, cell_atoms);
+      hipLaunchKernelGGL(nb_gather, dim3((nall + T - 1) / T), dim3(T), 0, st, x, cell_atoms, nall, xs);
     }
     if ((e = hipMemsetAsync(numneigh, 0, sizeof(int) * (size_t) (inum + 1), st)) != hipSuccess) return e;
     if (inum > 0) {
-      hipLaunchKernelGGL(nb_walk<false>, dim3((inum + T - 1) / T), dim3(T), 0, st, g, x, inum, cutoff * cutoff, cell_start,
-                         cell_atoms, numneigh, (const int *) nullptr, (int *) nullptr, d_info + 1);
+      hipLaunchKernelGGL(nb_walk<false>, dim3((nall + T - 1) / T), dim3(T), 0, st, g, x, inum, cutoff * cutoff, cell_start,
+                         cell_atoms, xs, nall, numneigh, (const int *) nullptr, (int *) nullptr, d_info + 1);
       hipLaunchKernelGGL(nb_iota, dim3((inum + T - 1) / T), dim3(T), 0, st, ilist, inum);
     }
     if ((e = hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, numneigh, first, inum + 1, st)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(d_info, first + inum, sizeof(int), hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
   } else if (inum > 0) {
-    hipLaunchKernelGGL(nb_walk<true>, dim3((inum + T - 1) / T), dim3(T), 0, st, g, x, inum, cutoff * cutoff, cell_start,
-                       cell_atoms, numneigh, first, neigh, (int *) nullptr);
+    hipLaunchKernelGGL(nb_walk<true>, dim3((nall + T - 1) / T), dim3(T), 0, st, g, x, inum, cutoff * cutoff, cell_start,
+                       cell_atoms, xs, nall, numneigh, first, neigh, (int *) nullptr);
   }
   return hipGetLastError();
 }
