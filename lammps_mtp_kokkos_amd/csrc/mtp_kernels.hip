@@ -43,22 +43,35 @@ namespace {
 #define MTP_PU 4   // times rows in flight per lane in the product passes
 #endif
 
+// The parameter block is read through the kernarg segment pointer (scalar loads from the constant cache) and the
+// pointer is made opaque at every phase boundary: the compiler then re-reads the few fields a phase needs instead
+// of carrying ~100 dwords of parameters in SGPRs across the whole atom loop (which spilled them into VGPR lanes:
+// a quarter of the per-atom VALU instructions were v_readlane / v_writelane).
+typedef const __attribute__((address_space(4))) MtpDevParams *KP;
+static __device__ __forceinline__ KP kp_fresh()
+{
+  KP k = (KP) __builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(k));
+  return k;
+}
+#define KP_FRESH() kp = kp_fresh()
+
 template <int PITCH> struct WaveLds {
   static constexpr int NT = PITCH - 2;
   double *M, *D, *tab, *nbx, *nby, *nbz, *nbr, *nbi;
   int *nbj, *nbjt, *cj;
   unsigned m_addr;   // LDS byte address of M
   __device__ __forceinline__ unsigned addr(const double *ptr) const { return m_addr + 8u * (unsigned) (ptr - M); }
-  __device__ __forceinline__ WaveLds(double *base, unsigned base_addr, const MtpDevParams &p)
+  __device__ __forceinline__ WaveLds(double *base, unsigned base_addr, KP kp)
   {
     // [g rows | dg rows | overlay | neighbour arrays]; the overlay holds the coordinate-power rows from
     // the tile build to the end of the basic-moment pass, and the moments / adjoints (later the
     // derivative-polynomial coefficients) from there on -- the two are never live together
     tab = base;
-    M = tab + (size_t) 2 * p.nslot * PITCH;
-    m_addr = base_addr + 8u * (unsigned) (2 * p.nslot * PITCH);
-    D = M + p.m_doubles;
-    nbx = M + p.ov_doubles;
+    M = tab + (size_t) 2 * kp->nslot * PITCH;
+    m_addr = base_addr + 8u * (unsigned) (2 * kp->nslot * PITCH);
+    D = M + kp->m_doubles;
+    nbx = M + kp->ov_doubles;
     nby = nbx + NT;
     nbz = nby + NT;
     nbr = nbz + NT;
@@ -72,7 +85,7 @@ template <int PITCH> struct WaveLds {
 // Phase 2: tables of one tile; columns [0, ntp) are written, ntp = nt rounded up to the
 // neighbour-group count with dummy neighbours sitting exactly on the cutoff (g = dg = 0).
 template <int PITCH>
-__device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTables &bt, const WaveLds<PITCH> &w,
+__device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const WaveLds<PITCH> &w,
                                            int t0, int cnt, int ntp, bool gather, bool powers, double xi0,
                                            double xi1, double xi2, int i, int itype, int lane)
 {
@@ -80,11 +93,11 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
     if (lane < ntp) {
       const bool real = t0 + lane < cnt;
       const int j = real ? w.cj[t0 + lane] : i;
-      double dx = 0, dy = 0, dz = 0, r = p.rmax;
+      double dx = 0, dy = 0, dz = 0, r = kp->rmax;
       if (real) {
-        dx = p.x[3 * (size_t) j] - xi0;
-        dy = p.x[3 * (size_t) j + 1] - xi1;
-        dz = p.x[3 * (size_t) j + 2] - xi2;
+        dx = kp->x[3 * (size_t) j] - xi0;
+        dy = kp->x[3 * (size_t) j + 1] - xi1;
+        dz = kp->x[3 * (size_t) j + 2] - xi2;
         r = sqrt(dx * dx + dy * dy + dz * dz);
       }
       w.nbx[lane] = dx;
@@ -93,28 +106,28 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
       w.nbr[lane] = r;
       w.nbi[lane] = 1.0 / r;
       w.nbj[lane] = j;
-      w.nbjt[lane] = real ? p.type[j] - 1 : itype;
+      w.nbjt[lane] = real ? kp->type[j] - 1 : itype;
     }
     wave_fence();
   }
   // lanes = (neighbour n, half h): one pass over the tile.  The Chebyshev values q_k(r) and derivatives are
   // shared by all radial functions of the neighbour; half h contracts them for mu = h, h+2, ... and writes
   // the g / dg rows of those mu; the coordinate-power rows are split x,y | z between the halves.
-  const int Mu = p.Mu, P = p.P, R = p.R;
-  const double mult = 2.0 * p.inv_span;
+  const int Mu = kp->Mu, P = kp->P, R = kp->R;
+  const double mult = 2.0 * kp->inv_span;
   const int n = lane & 31, h = lane >> 5;
   if (n < ntp) {
     const double r = w.nbr[n], inv = w.nbi[n];
     const int jt = w.nbjt[n];
-    const double d = r - p.rmax;
-    const double ksi = (2.0 * r - (p.rmin + p.rmax)) * p.inv_span;
+    const double d = r - kp->rmax;
+    const double ksi = (2.0 * r - (kp->rmin + kp->rmax)) * kp->inv_span;
     double *col = w.tab + n;
     if (R == 8) {   // the MLIP default: basis in registers, coefficients in bursts of 16-byte reads
       double qv[8], ev[8];
-      qv[0] = p.scaling * (d * d);
-      qv[1] = p.scaling * (ksi * d * d);
-      ev[0] = p.scaling * 2.0 * d;
-      ev[1] = p.scaling * (mult * d * d + 2.0 * ksi * d);
+      qv[0] = kp->scaling * (d * d);
+      qv[1] = kp->scaling * (ksi * d * d);
+      ev[0] = kp->scaling * 2.0 * d;
+      ev[1] = kp->scaling * (mult * d * d + 2.0 * ksi * d);
 #pragma unroll
       for (int ri = 2; ri < 8; ri++) {   // mtp_rb_chevbyshev_basis.cpp:29-54
         qv[ri] = 2.0 * ksi * qv[ri - 1] - qv[ri - 2];
@@ -124,7 +137,7 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
         const int4 *sl4 = reinterpret_cast<const int4 *>(bt.slot + mu * MTP_PSTRIDE);
         const int4 sa = sl4[0], sb = sl4[1], sc = sl4[2];
         const int sv[MTP_PSTRIDE] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w, sc.x, sc.y, sc.z, sc.w};
-        const double2 *c2 = reinterpret_cast<const double2 *>(bt.radial + ((itype * p.Sp + jt) * Mu + mu) * 8);
+        const double2 *c2 = reinterpret_cast<const double2 *>(bt.radial + ((itype * kp->Sp + jt) * Mu + mu) * 8);
         const double2 c01 = c2[0], c23 = c2[1], c45 = c2[2], c67 = c2[3];
         const double cc[8] = {c01.x, c01.y, c23.x, c23.y, c45.x, c45.y, c67.x, c67.y};
         double val = cc[0] * qv[0], der = cc[0] * ev[0];
@@ -141,7 +154,7 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
             const double g = val * rp;
             if (sidx >= 0) {
               col[sidx * PITCH] = g;                                       // f_mu / r^nu
-              col[(p.nslot + sidx) * PITCH] = der * rp - nu * g * inv;     // d/dr (f_mu / r^nu)
+              col[(kp->nslot + sidx) * PITCH] = der * rp - nu * g * inv;     // d/dr (f_mu / r^nu)
             }
             rp *= inv;
           }
@@ -150,9 +163,9 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
     } else {
       for (int mu = h; mu < Mu; mu += 2) {
         const int *sl = bt.slot + mu * MTP_PSTRIDE;
-        const double *c = bt.radial + ((itype * p.Sp + jt) * Mu + mu) * R;
-        double q0 = p.scaling * (d * d), q1 = p.scaling * (ksi * d * d);
-        double e0 = p.scaling * 2.0 * d, e1 = p.scaling * (mult * d * d + 2.0 * ksi * d);
+        const double *c = bt.radial + ((itype * kp->Sp + jt) * Mu + mu) * R;
+        double q0 = kp->scaling * (d * d), q1 = kp->scaling * (ksi * d * d);
+        double e0 = kp->scaling * 2.0 * d, e1 = kp->scaling * (mult * d * d + 2.0 * ksi * d);
         double val = c[0] * q0, der = c[0] * e0;
         if (R > 1) {
           val += c[1] * q1;
@@ -174,7 +187,7 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
           const double g = val * rp;
           if (sidx >= 0) {
             col[sidx * PITCH] = g;
-            col[(p.nslot + sidx) * PITCH] = der * rp - nu * g * inv;
+            col[(kp->nslot + sidx) * PITCH] = der * rp - nu * g * inv;
           }
           rp *= inv;
         }
@@ -182,7 +195,7 @@ __device__ __forceinline__ void build_tile(const MtpDevParams &p, const BlockTab
     }
     if (powers) {   // rows of one axis: [q] = u^q
       const double u0 = h == 0 ? w.nbx[n] : w.nbz[n];
-      double *pc = col + (size_t) (2 * p.nslot + (h == 0 ? 0 : 2 * P)) * PITCH;
+      double *pc = col + (size_t) (2 * kp->nslot + (h == 0 ? 0 : 2 * P)) * PITCH;
       double cur = 1.0;
       pc[0] = 1.0;
       for (int q = 1; q < P; q++) {
@@ -292,19 +305,19 @@ template <int C> __device__ __forceinline__ double poly_eval(unsigned coef, cons
 // GRADE (fused candidate vectors): W[mu] collects this lane's share of W_mu(n) = sum_{s in mu} P_s(r_n) / r_n^nu
 // (pair_mtp_extrapolation.cpp:193-198), again through P_s = (r . grad P_s) / nu; rw = r^-NU on entry.
 template <int NU, int DEG, int PITCH, bool GRADE>
-__device__ __forceinline__ void force_degree(const MtpDevParams &p, unsigned pcol, unsigned pcoef, int part, double x,
+__device__ __forceinline__ void force_degree(KP kp, unsigned pcol, unsigned pcoef, int part, double x,
                                              double y, double z, double *m, double &UA, double &VA, double &UB,
                                              double &VB, const int *smu, double inv, double rw, double *W)
 {
   if constexpr (NU <= DEG) {
     constexpr int C = NU * (NU + 1) / 2;   // monomials of degree NU-1
-    if (NU < p.P) {
-      const int s0 = p.deg_first[NU], cnt = p.deg_first[NU + 1] - s0;
+    if (NU < kp->P) {
+      const int s0 = kp->deg_first[NU], cnt = kp->deg_first[NU + 1] - s0;
       const double inv_nu = 1.0 / NU;
-      const unsigned dgo = 8u * (unsigned) (p.nslot * PITCH);
+      const unsigned dgo = 8u * (unsigned) (kp->nslot * PITCH);
       const double wa = GRADE ? (part ? z : x) * (rw * inv_nu) : 0.0, wb = GRADE ? y * (rw * inv_nu) : 0.0;
       {
-        unsigned ca = pcoef + 8u * (unsigned) (p.deg_coef[NU] + part * 2 * C);
+        unsigned ca = pcoef + 8u * (unsigned) (kp->deg_coef[NU] + part * 2 * C);
         unsigned cg = pcol + 8u * (unsigned) (s0 * PITCH);
         for (int it = 0; it < cnt; it++) {
           const double g = lds_ld(cg, 0), dg = lds_ld(cg + dgo, 0);
@@ -325,7 +338,7 @@ __device__ __forceinline__ void force_degree(const MtpDevParams &p, unsigned pco
         const int si = 2 * it + part;
         const bool ok = si < cnt;
         const int sc = ok ? si : 0;
-        const unsigned cb = pcoef + 8u * (unsigned) (p.deg_coef[NU] + sc * 3 * C + C);
+        const unsigned cb = pcoef + 8u * (unsigned) (kp->deg_coef[NU] + sc * 3 * C + C);
         const unsigned cg = pcol + 8u * (unsigned) ((s0 + sc) * PITCH);
         const double g_raw = lds_ld(cg, 0), dg_raw = lds_ld(cg + dgo, 0);
         const double G = poly_eval<C>(cb, m);
@@ -347,49 +360,51 @@ __device__ __forceinline__ void force_degree(const MtpDevParams &p, unsigned pco
         m[C + NU] = z * m[T0 + NU - 1];
 #pragma unroll
         for (int i = 0; i < C; i++) m[i] *= x;
-        force_degree<NU + 1, DEG, PITCH, GRADE>(p, pcol, pcoef, part, x, y, z, m, UA, VA, UB, VB, smu, inv, rw * inv, W);
+        force_degree<NU + 1, DEG, PITCH, GRADE>(kp, pcol, pcoef, part, x, y, z, m, UA, VA, UB, VB, smu, inv, rw * inv, W);
       }
     }
   }
 }
 
 template <int KL, int KB, int PITCH, bool GRADE, int DEG>
-__global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
+__global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_arg)
 {
   constexpr int NT = PITCH - 2;          // neighbours per tile (32 or 16)
   constexpr int NG = 64 / KL;            // neighbour groups in the wavefront
   constexpr int NPG = NT / NG;           // neighbours per group per tile
   static_assert(NT == 32, "the force phase maps lanes to (32 neighbours) x (2 halves)");
 
+  (void) p_arg;   // the only kernel argument: it starts the kernarg segment
+  KP kp = (KP) __builtin_amdgcn_kernarg_segment_ptr();
   extern __shared__ double lds[];
   unsigned char *sh = reinterpret_cast<unsigned char *>(lds);
   // ---- 0. workgroup-shared tables ---------------------------------------------------------
-  for (int o = threadIdx.x * 16; o < p.blob_bytes; o += blockDim.x * 16)
-    *reinterpret_cast<uint4 *>(sh + o) = *reinterpret_cast<const uint4 *>(p.blob + o);
+  for (int o = threadIdx.x * 16; o < kp->blob_bytes; o += blockDim.x * 16)
+    *reinterpret_cast<uint4 *>(sh + o) = *reinterpret_cast<const uint4 *>(kp->blob + o);
   __syncthreads();
   BlockTables bt;
-  bt.rows = reinterpret_cast<const MtpRow8 *>(sh + p.off_rows);
-  bt.level = reinterpret_cast<const int *>(sh + p.off_level);
-  bt.slot = reinterpret_cast<const int *>(sh + p.off_slot);
-  bt.radial = reinterpret_cast<const double *>(sh + p.off_radial);
-  bt.seed_idx = reinterpret_cast<const int *>(sh + p.off_seed_idx);
-  bt.seed_val = reinterpret_cast<const double *>(sh + p.off_seed_val);
-  bt.map = reinterpret_cast<const int *>(sh + p.off_map);
-  bt.lin = reinterpret_cast<const double *>(sh + p.off_lin);
-  bt.pack = reinterpret_cast<const int *>(sh + p.off_pack);
-  bt.coef = reinterpret_cast<const int *>(sh + p.off_coef);
-  bt.smu = reinterpret_cast<const int *>(sh + p.off_smu);
-  const bool rows_lds = p.rows_in_lds != 0;
+  bt.rows = reinterpret_cast<const MtpRow8 *>(sh + kp->off_rows);
+  bt.level = reinterpret_cast<const int *>(sh + kp->off_level);
+  bt.slot = reinterpret_cast<const int *>(sh + kp->off_slot);
+  bt.radial = reinterpret_cast<const double *>(sh + kp->off_radial);
+  bt.seed_idx = reinterpret_cast<const int *>(sh + kp->off_seed_idx);
+  bt.seed_val = reinterpret_cast<const double *>(sh + kp->off_seed_val);
+  bt.map = reinterpret_cast<const int *>(sh + kp->off_map);
+  bt.lin = reinterpret_cast<const double *>(sh + kp->off_lin);
+  bt.pack = reinterpret_cast<const int *>(sh + kp->off_pack);
+  bt.coef = reinterpret_cast<const int *>(sh + kp->off_coef);
+  bt.smu = reinterpret_cast<const int *>(sh + kp->off_smu);
+  const bool rows_lds = kp->rows_in_lds != 0;
 
   const int lane = threadIdx.x & 63;
   // wave-uniform by construction: tell the compiler, so per-atom state lives in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wpb = blockDim.x >> 6;
   const int kl = lane & (KL - 1), q = lane / KL;
-  const unsigned wave_off = (p.blob_bytes >> 3) + wave * p.wave_doubles;   // doubles
+  const unsigned wave_off = (kp->blob_bytes >> 3) + wave * kp->wave_doubles;   // doubles
   const unsigned lds0 = (unsigned) (size_t) (lds_cdouble *) lds;            // static cast of the array itself
-  const WaveLds<PITCH> w(lds + wave_off, lds0 + 8u * wave_off, p);
-  const int ns = p.nslot, P = p.P;
+  const WaveLds<PITCH> w(lds + wave_off, lds0 + 8u * wave_off, kp);
+  const int ns = kp->nslot, P = kp->P;
 
   // per-lane descriptors of the basics this lane owns (k = kl + KL t): LDS row bases for
   // this lane's neighbour column q; the partner row (dg, next power) is +PITCH
@@ -398,7 +413,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
 #pragma unroll
   for (int t = 0; t < KB; t++) {
     const int k = kl + KL * t;
-    kval[t] = k < p.B;
+    kval[t] = k < kp->B;
     const int pk = kval[t] ? bt.pack[k] : 0;
     const int a = (pk >> 8) & 15, b = (pk >> 12) & 15, c = (pk >> 16) & 15;
     // rows: g at slot (dg at ns + slot is read by the force phase); px/py/pz point at the row BELOW u^a
@@ -418,20 +433,21 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
   unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #endif
 
-  for (int ii = blockIdx.x * wpb + wave; ii < p.inum; ii += gridDim.x * wpb) {
+  for (int ii = blockIdx.x * wpb + wave; ii < kp->inum; ii += gridDim.x * wpb) {
     // ii is wave-uniform, so is everything loaded through it: keep it in SGPRs
-    const int i = __builtin_amdgcn_readfirstlane(p.ilist[ii]);
-    const int itype = __builtin_amdgcn_readfirstlane(p.type[i] - 1);
-    if (itype < 0 || itype >= p.Sp) {   // pair_mtp.cpp:91-93
-      if (lane == 0) atomicExch(p.err_flag, 1);
+    const int i = __builtin_amdgcn_readfirstlane(kp->ilist[ii]);
+    const int itype = __builtin_amdgcn_readfirstlane(kp->type[i] - 1);
+    if (itype < 0 || itype >= kp->Sp) {   // pair_mtp.cpp:91-93
+      if (lane == 0) atomicExch(kp->err_flag, 1);
       continue;
     }
-    const double xi0 = uniform_f64(p.x[3 * (size_t) i]), xi1 = uniform_f64(p.x[3 * (size_t) i + 1]),
-                 xi2 = uniform_f64(p.x[3 * (size_t) i + 2]);
-    const int jbeg = __builtin_amdgcn_readfirstlane(p.first[ii]);
-    const int jnum = __builtin_amdgcn_readfirstlane(p.first[ii + 1]) - jbeg;
+    const double xi0 = uniform_f64(kp->x[3 * (size_t) i]), xi1 = uniform_f64(kp->x[3 * (size_t) i + 1]),
+                 xi2 = uniform_f64(kp->x[3 * (size_t) i + 2]);
+    const int jbeg = __builtin_amdgcn_readfirstlane(kp->first[ii]);
+    const int jnum = __builtin_amdgcn_readfirstlane(kp->first[ii + 1]) - jbeg;
 
     STAMP(0);   // loop head: ilist/type/x/first loads issue
+    KP_FRESH();
     // ---- 1. compaction (the first NT survivors go straight into the tile arrays) --------
     int cnt = 0;
     for (int c0 = 0; c0 < jnum; c0 += 128) {
@@ -443,14 +459,14 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
       for (int u = 0; u < 2; u++) {
         const int jj = c0 + 64 * u + lane;
         ok2[u] = jj < jnum;
-        j2[u] = p.neigh[jbeg + min(jj, jnum - 1)] & MTP_NEIGHMASK;
+        j2[u] = kp->neigh[jbeg + min(jj, jnum - 1)] & MTP_NEIGHMASK;
       }
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        jt2[u] = p.type[j2[u]] - 1;
-        d2[u][0] = p.x[3 * (size_t) j2[u]];
-        d2[u][1] = p.x[3 * (size_t) j2[u] + 1];
-        d2[u][2] = p.x[3 * (size_t) j2[u] + 2];
+        jt2[u] = kp->type[j2[u]] - 1;
+        d2[u][0] = kp->x[3 * (size_t) j2[u]];
+        d2[u][1] = kp->x[3 * (size_t) j2[u] + 1];
+        d2[u][2] = kp->x[3 * (size_t) j2[u] + 2];
       }
 #pragma unroll
       for (int u = 0; u < 2; u++) {
@@ -459,20 +475,20 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
         bool in = false;
         double dx = 0, dy = 0, dz = 0, r2 = 1.0;
         if (ok2[u]) {
-          if (jt < 0 || jt >= p.Sp) {   // pair_mtp.cpp:116-118
-            atomicExch(p.err_flag, 1);
+          if (jt < 0 || jt >= kp->Sp) {   // pair_mtp.cpp:116-118
+            atomicExch(kp->err_flag, 1);
           } else {
             dx = d2[u][0] - xi0;
             dy = d2[u][1] - xi1;
             dz = d2[u][2] - xi2;
             r2 = dx * dx + dy * dy + dz * dz;
-            in = !(r2 > p.cutsq);   // pair_mtp.cpp:123
+            in = !(r2 > kp->cutsq);   // pair_mtp.cpp:123
           }
         }
         const unsigned long long m = __ballot(in);
         if (in) {
           const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-          if (pos < p.cj_cap) w.cj[pos] = j;   // a list longer than the declared max_numneigh is reported below
+          if (pos < kp->cj_cap) w.cj[pos] = j;   // a list longer than the declared max_numneigh is reported below
           if (pos < NT) {
             const double r = sqrt(r2);
             w.nbx[pos] = dx;
@@ -487,9 +503,9 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
         cnt += __builtin_amdgcn_readfirstlane(__popcll(m));
       }
     }
-    if (cnt > p.cj_cap) {   // the caller's max_numneigh sized the id array: refuse instead of overrunning LDS
-      if (lane == 0) atomicExch(p.err_flag, 2);
-      cnt = p.cj_cap;
+    if (cnt > kp->cj_cap) {   // the caller's max_numneigh sized the id array: refuse instead of overrunning LDS
+      if (lane == 0) atomicExch(kp->err_flag, 2);
+      cnt = kp->cj_cap;
     }
     {   // dummy neighbours pad tile 0 to a multiple of NG
       const int pos = cnt + lane;
@@ -497,8 +513,8 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
         w.nbx[pos] = 0.0;
         w.nby[pos] = 0.0;
         w.nbz[pos] = 0.0;
-        w.nbr[pos] = p.rmax;
-        w.nbi[pos] = 1.0 / p.rmax;
+        w.nbr[pos] = kp->rmax;
+        w.nbi[pos] = 1.0 / kp->rmax;
         w.nbj[pos] = i;
         w.nbjt[pos] = itype;
       }
@@ -506,6 +522,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     wave_fence();
 
     STAMP(1);   // compaction
+    KP_FRESH();
     // ---- 2+3. tiles: tables, then basic moments in registers ------------------------------
     double acc[KB];
 #pragma unroll
@@ -513,8 +530,9 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     const int ntiles = (cnt + NT - 1) / NT;
     for (int tile = 0; tile < ntiles; tile++) {
       const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-      build_tile<PITCH>(p, bt, w, t0, cnt, ntp, tile > 0, true, xi0, xi1, xi2, i, itype, lane);
+      build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, tile > 0, true, xi0, xi1, xi2, i, itype, lane);
       STAMP(2);   // tile tables
+    KP_FRESH();
 #pragma unroll
       for (int m = 0; m < NPG; m++) {
         if (m * NG < ntp) {
@@ -538,14 +556,15 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
       if (ntiles > 1) wave_fence();
     }
     STAMP(3);   // basic moments
+    KP_FRESH();
     // sum over the neighbour groups, then moments + adjoints into LDS
 #pragma unroll
     for (int t = 0; t < KB; t++) {
       if (NG >= 4) acc[t] = pair_sum16(acc[t]);   // KL = 16: groups differ in lane bits 4 and 5
       if (NG >= 2) acc[t] = pair_sum32(acc[t]);
     }
-    for (int m = p.B + lane; m < p.A; m += 64) w.M[m] = 0.0;
-    for (int m = lane; m < p.A; m += 64) w.D[m] = 0.0;
+    for (int m = kp->B + lane; m < kp->A; m += 64) w.M[m] = 0.0;
+    for (int m = lane; m < kp->A; m += 64) w.D[m] = 0.0;
     if (q == 0) {
 #pragma unroll
       for (int t = 0; t < KB; t++)
@@ -554,42 +573,45 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     wave_fence();
 
     // ---- 4a. products, level by level (pair_mtp.cpp:196-201) -----------------------------
-    if (rows_lds) products_forward<MTP_PU>(bt.rows, bt.level, p.nlevels, w.M, lane);
-    else products_forward<MTP_PU>(p.rows, bt.level, p.nlevels, w.M, lane);
+    if (rows_lds) products_forward<MTP_PU>(bt.rows, bt.level, kp->nlevels, w.M, lane);
+    else products_forward<MTP_PU>(kp->rows, bt.level, kp->nlevels, w.M, lane);
     STAMP(4);   // products forward
+    KP_FRESH();
     // ---- candidate vector, species and linear blocks (pair_mtp_extrapolation.cpp:235-252) ----
     if (GRADE) {
-      double *crow = p.cvec + (size_t) ii * p.cpad + p.Sp * p.Sp * p.Mu * p.R;
-      for (int k = lane; k < p.Sp; k += 64) crow[k] = k == itype ? 1.0 : 0.0;
-      if (p.scalars_in_lds)
-        for (int k = lane; k < p.S; k += 64) crow[p.Sp + k] = w.M[bt.map[k]];
+      double *crow = kp->cvec + (size_t) ii * kp->cpad + kp->Sp * kp->Sp * kp->Mu * kp->R;
+      for (int k = lane; k < kp->Sp; k += 64) crow[k] = k == itype ? 1.0 : 0.0;
+      if (kp->scalars_in_lds)
+        for (int k = lane; k < kp->S; k += 64) crow[kp->Sp + k] = w.M[bt.map[k]];
       else
-        for (int k = lane; k < p.S; k += 64) crow[p.Sp + k] = w.M[p.g_map[k]];
+        for (int k = lane; k < kp->S; k += 64) crow[kp->Sp + k] = w.M[kp->g_map[k]];
     }
     // ---- site energy (pair_mtp.cpp:204-212) ----------------------------------------------
     double e = 0.0;
     // (two code paths per table home, LDS blob or HBM/L2: no pointer selects between address spaces, see below)
-    if (p.scalars_in_lds)
-      for (int k = lane; k < p.S; k += 64) e += bt.lin[k] * w.M[bt.map[k]];
+    if (kp->scalars_in_lds)
+      for (int k = lane; k < kp->S; k += 64) e += bt.lin[k] * w.M[bt.map[k]];
     else
-      for (int k = lane; k < p.S; k += 64) e += p.g_lin[k] * w.M[p.g_map[k]];
-    e = wave_sum(e) + p.species_coeffs[itype];
+      for (int k = lane; k < kp->S; k += 64) e += kp->g_lin[k] * w.M[kp->g_map[k]];
+    e = wave_sum(e) + kp->species_coeffs[itype];
     // ---- 4b. adjoints (pair_mtp.cpp:217-233) ----------------------------------------------
-    if (p.scalars_in_lds)
-      for (int k = lane; k < p.nseed; k += 64) w.D[bt.seed_idx[k]] = bt.seed_val[k];
+    if (kp->scalars_in_lds)
+      for (int k = lane; k < kp->nseed; k += 64) w.D[bt.seed_idx[k]] = bt.seed_val[k];
     else
-      for (int k = lane; k < p.nseed; k += 64) w.D[p.g_seed_idx[k]] = p.g_seed_val[k];
+      for (int k = lane; k < kp->nseed; k += 64) w.D[kp->g_seed_idx[k]] = kp->g_seed_val[k];
     wave_fence();
     STAMP(5);   // energy + seeds
-    if (rows_lds) products_backward<MTP_PU>(bt.rows, bt.level, p.nlevels, w.M, w.D, lane);
-    else products_backward<MTP_PU>(p.rows, bt.level, p.nlevels, w.M, w.D, lane);
+    KP_FRESH();
+    if (rows_lds) products_backward<MTP_PU>(bt.rows, bt.level, kp->nlevels, w.M, w.D, lane);
+    else products_backward<MTP_PU>(kp->rows, bt.level, kp->nlevels, w.M, w.D, lane);
 
     STAMP(6);   // products backward
+    KP_FRESH();
     // ---- 5. forces ---------------------------------------------------------------------------
     // the (now free) moment region receives the coefficient blocks of the derivative polynomials:
     // basic k = (slot s; a, b, c) puts a D_k at the d/dx coefficient of x^(a-1) y^b z^c, b D_k and c D_k alike
-    if (!p.coef_dense) {   // monomials the potential does not list
-      for (int k = lane; k < p.coef_total; k += 64) w.M[k] = 0.0;
+    if (!kp->coef_dense) {   // monomials the potential does not list
+      for (int k = lane; k < kp->coef_total; k += 64) w.M[k] = 0.0;
       wave_fence();
     }
     {
@@ -598,15 +620,15 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
       int2 tg[ROUNDS];
 #pragma unroll
       for (int u = 0; u < ROUNDS; u++) {   // all reads first: one LDS round trip
-        const int k = lane + 64 * u, kc = min(k, p.B - 1);
+        const int k = lane + 64 * u, kc = min(k, kp->B - 1);
         dd[u] = w.D[kc];
         tg[u] = reinterpret_cast<const int2 *>(bt.coef)[kc];
       }
 #pragma unroll
       for (int u = 0; u < ROUNDS; u++) {
         const int k = lane + 64 * u;
-        const bool ok = k < p.B;
-        if (GRADE && p.dbasic && k < KL * KB) p.dbasic[(size_t) ii * p.dpad + k] = ok ? dd[u] : 0.0;   // read back by mtp_cvec_kernel
+        const bool ok = k < kp->B;
+        if (GRADE && kp->dbasic && k < KL * KB) kp->dbasic[(size_t) ii * kp->dpad + k] = ok ? dd[u] : 0.0;   // read back by mtp_cvec_kernel
         if (ok) {
           const unsigned t0 = (unsigned) tg[u].x, t1 = (unsigned) tg[u].y;
           const unsigned tx = t0 & 0xffffu, ty = t0 >> 16, tz = t1 & 0xffffu;
@@ -618,6 +640,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     }
     wave_fence();
     STAMP(9);   // coefficient blocks
+    KP_FRESH();
     // per-lane partial sums: force on i (3), virial (6)
     double fi0 = 0, fi1 = 0, fi2 = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
     {
@@ -627,16 +650,16 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
       double crad = 0.0;
       for (int tile = 0; tile < ntiles; tile++) {
         const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-        if (ntiles > 1) build_tile<PITCH>(p, bt, w, t0, cnt, ntp, true, false, xi0, xi1, xi2, i, itype, lane);
+        if (ntiles > 1) build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, true, false, xi0, xi1, xi2, i, itype, lane);
         // columns past ntp hold stale (finite or not) data: their lanes are masked at the end
         const double x = w.nbx[n], y = w.nby[n], z = w.nbz[n], inv = w.nbi[n];
         double UA = 0.0, VA = 0.0, UB = 0.0, VB = 0.0, S0 = 0.0;
         double Wm[4] = {0.0, 0.0, 0.0, 0.0};
-        const bool fused = GRADE && p.grade_fused;
+        const bool fused = GRADE && kp->grade_fused;
         {   // rank 0: P_s = D_k, no gradient
           unsigned cg = pcol + 8u * (unsigned) (ns * PITCH);
-          for (int sidx = 0; sidx < p.deg_first[1]; sidx++) {
-            const double dk = w.M[p.deg_coef[0] + sidx];
+          for (int sidx = 0; sidx < kp->deg_first[1]; sidx++) {
+            const double dk = w.M[kp->deg_coef[0] + sidx];
             S0 = fma(lds_ld(cg, 0), dk, S0);
             if (GRADE) {
               const int mu = bt.smu[sidx];
@@ -648,16 +671,16 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
         }
         double mono[DEG * (DEG + 1) / 2];
         mono[0] = 1.0;
-        force_degree<1, DEG, PITCH, GRADE>(p, pcol, w.m_addr, part, x, y, z, mono, UA, VA, UB, VB, bt.smu, inv, inv, Wm);
+        force_degree<1, DEG, PITCH, GRADE>(kp, pcol, w.m_addr, part, x, y, z, mono, UA, VA, UB, VB, bt.smu, inv, inv, Wm);
         if (fused) {
           // c[jt][mu][ri] += sum_n [type_n = jt] Q_ri(r_n) W_mu(n)  (pair_mtp_extrapolation.cpp:193-198, 323-329):
           // half h of the wavefront reduces the 32 (mu, ri) entries of jt = h over its 32 neighbour lanes
           double qv[8];
           {
-            const double r = w.nbr[n], d = r - p.rmax;
-            const double ksi = (2.0 * r - (p.rmin + p.rmax)) * p.inv_span;
-            qv[0] = p.scaling * (d * d);
-            qv[1] = p.scaling * (ksi * d * d);
+            const double r = w.nbr[n], d = r - kp->rmax;
+            const double ksi = (2.0 * r - (kp->rmin + kp->rmax)) * kp->inv_span;
+            qv[0] = kp->scaling * (d * d);
+            qv[1] = kp->scaling * (ksi * d * d);
 #pragma unroll
             for (int ri = 2; ri < 8; ri++) qv[ri] = 2.0 * ksi * qv[ri - 1] - qv[ri - 2];
           }
@@ -684,16 +707,16 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
         if (valid) {
           const size_t j = (size_t) w.nbj[n];
 #ifndef MTP_EXP_NOSCATTER   // timing experiment only (wrong results)
-          unsafeAtomicAdd(&p.f[3 * j + (part ? 2 : 0)], -Fa);   // pair_mtp.cpp:252-254
-          if (part == 0) unsafeAtomicAdd(&p.f[3 * j + 1], -Fy);
+          unsafeAtomicAdd(&kp->f[3 * j + (part ? 2 : 0)], -Fa);   // pair_mtp.cpp:252-254
+          if (part == 0) unsafeAtomicAdd(&kp->f[3 * j + 1], -Fy);
 #else
-          if (Fa + Fy == 12345.678) p.f[3 * j] = Fa;   // keeps the values live
+          if (Fa + Fy == 12345.678) kp->f[3 * j] = Fa;   // keeps the values live
 #endif
         }
         fi0 += Fx;
         fi1 += Fy;
         fi2 += Fz;
-        if (p.vflag && valid) {   // pair_mtp.cpp:257-277 (linear in F: each half tallies its components)
+        if (kp->vflag && valid) {   // pair_mtp.cpp:257-277 (linear in F: each half tallies its components)
           v0 -= Fx * x;
           v1 -= Fy * y;
           v2 -= Fz * z;
@@ -703,18 +726,19 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
         }
         if (ntiles > 1) wave_fence();
       }
-      if (GRADE && p.grade_fused) {   // radial block of the row: block (itype, jt), zeros elsewhere
-        const int MuR = p.Mu * 8, SMR = p.Sp * MuR;
-        double *crow = p.cvec + (size_t) ii * p.cpad;
-        for (int e = lane; e < p.Sp * SMR; e += 64)
+      if (GRADE && kp->grade_fused) {   // radial block of the row: block (itype, jt), zeros elsewhere
+        const int MuR = kp->Mu * 8, SMR = kp->Sp * MuR;
+        double *crow = kp->cvec + (size_t) ii * kp->cpad;
+        for (int e = lane; e < kp->Sp * SMR; e += 64)
           if (e / SMR != itype) crow[e] = 0.0;
-        if (part < p.Sp && n < MuR) crow[(itype * p.Sp + part) * MuR + n] = crad;
+        if (part < kp->Sp && n < MuR) crow[(itype * kp->Sp + part) * MuR + n] = crad;
       }
     }
     STAMP(7);   // forces
+    KP_FRESH();
     // ---- per-atom totals over the 64 lanes: lane v < 9 ends up with value v --------------------
     double tot;
-    if (p.vflag) {
+    if (kp->vflag) {
       double part16[16] = {fi0, fi1, fi2, v0, v1, v2, v3, v4, v5, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       Butterfly<16>::run(part16, lane);
       tot = part16[0];
@@ -733,25 +757,26 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p)
     tot = pair_sum32(pair_sum16(tot));
     if (lane < 9) {
       if (lane < 3) {
-        unsafeAtomicAdd(&p.f[3 * (size_t) i + lane], tot);   // pair_mtp.cpp:248-250
-      } else if (p.vflag) {
+        unsafeAtomicAdd(&kp->f[3 * (size_t) i + lane], tot);   // pair_mtp.cpp:248-250
+      } else if (kp->vflag) {
         tally += tot;
-        if ((p.vflag & 4) && p.vatom) p.vatom[6 * (size_t) i + (lane - 3)] += tot;
+        if ((kp->vflag & 4) && kp->vatom) kp->vatom[6 * (size_t) i + (lane - 3)] += tot;
       }
     }
     if (lane == 9) {
-      if ((p.eflag & 2) && p.eatom) p.eatom[i] = e;
-      if (p.eflag & 1) tally += e;
+      if ((kp->eflag & 2) && kp->eatom) kp->eatom[i] = e;
+      if (kp->eflag & 1) tally += e;
     }
     wave_fence();
     STAMP(8);   // per-atom totals
+    KP_FRESH();
   }
 #ifdef MTP_STAMPS
-  if (lane == 0 && p.stamps)
-    for (int k = 0; k < 10; k++) atomicAdd(p.stamps + k, st_acc[k]);
+  if (lane == 0 && kp->stamps)
+    for (int k = 0; k < 10; k++) atomicAdd(kp->stamps + k, st_acc[k]);
 #endif
   if (lane >= 3 && lane <= 9 && tally != 0.0) {
-    double *slot = p.ev_slots + 8 * (size_t) ((blockIdx.x * wpb + wave) % MTP_EV_SLOTS);
+    double *slot = kp->ev_slots + 8 * (size_t) ((blockIdx.x * wpb + wave) % MTP_EV_SLOTS);
     unsafeAtomicAdd(&slot[lane == 9 ? 0 : lane - 2], tally);
   }
 }
