@@ -117,7 +117,7 @@ def main():
     f = torch.zeros((plan.nall, 3), dtype=torch.float64, device=dev)
     ev = torch.zeros(8, dtype=torch.float64, device=dev)
     halo = HaloExchange(plan, dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = capi.use_private_torch_stream(dev).cuda_stream   # torch ops, collectives and the HIP kernels on ONE stream
     EFLAG, VFLAG = 1, 1
     grades_t = torch.zeros(plan.nall, dtype=torch.float64, device=dev) if grade else None
     maxg_t = torch.zeros(1, dtype=torch.float64, device=dev) if grade else None

@@ -8,7 +8,10 @@
  * Threading: one context per rank/GPU; calls on one context must be serialised by the
  * caller (the reference is not re-entrant either: member scratch buffers,
  * LAMMPS/ML-MTP/pair_mtp.h:70-83).  Device work is ordered on the stream given to the
- * `_device` entry points (the context's own stream otherwise).
+ * `_device` entry points.  A NULL stream means the context's own stream, which is created
+ * NON-BLOCKING: it does not synchronise with the legacy default stream, so a caller whose
+ * other GPU work runs on the default stream (PyTorch's default) must pass a real stream
+ * handle that its own work is ordered on, or synchronise around the calls.
  */
 #ifndef MTP_MI355X_H
 #define MTP_MI355X_H

@@ -67,6 +67,17 @@ def lib():
     return _lib
 
 
+def use_private_torch_stream(device):
+    """PyTorch's default stream is the legacy null stream (handle 0), and a null handle asks this library for the
+    context's own NON-BLOCKING stream -- torch work and the library's kernels would then not be ordered with respect
+    to each other.  Drivers that mix both call this once: it makes a real stream current for torch and returns its
+    handle for the library's `stream` arguments (collectives issued from torch follow the current stream too)."""
+    import torch
+    s = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(s)
+    return s
+
+
 def _np(a, ty):
     return None if a is None else a.ctypes.data_as(C.POINTER(ty))
 

@@ -23,6 +23,7 @@ def main():
     backend = os.environ.get("MTP_BENCH_BACKEND", "nccl")
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    capi.use_private_torch_stream(dev)   # one real stream for torch ops, collectives and the library
     dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     pos, box = mtpgen.bcc_lattice(6, 6, 8, seed=91)
     types = (np.random.default_rng(3).random(len(pos)) < 0.1).astype(np.int32) + 1

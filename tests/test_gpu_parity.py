@@ -218,7 +218,7 @@ def test_device_pointer_path_matches_host_path():
     va = torch.zeros((s.nall, 6), dtype=torch.float64, device=dev)
     ev = torch.zeros(8, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
-    st = torch.cuda.current_stream().cuda_stream
+    st = torch.cuda.current_stream().cuda_stream    # null handle under pytest: the context's own stream (synchronised above)
     for _ in range(2):                                   # forces accumulate over calls
         ctx.compute_device(x, ty, f, eflag=3, vflag=4, eatom_t=ea, vatom_t=va, ev_t=ev, stream=st)
     ctx.synchronize(st)

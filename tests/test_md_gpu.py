@@ -57,3 +57,37 @@ def test_config1_ten_nve_steps_match_oracle_and_conserve_energy():
     assert np.abs(pg - pc).max() < 1e-10 and np.abs(vg - vc).max() < 1e-9
     assert np.abs(eg - ec).max() < 1e-8
     assert np.abs(eg - eg[0]).max() < 2e-4 * 256      # NVE drift over 10 fs, eV
+
+
+@pytest.mark.gpu
+def test_device_resident_nve_matches_host_driven_loop():
+    """the same ten steps with positions, velocities, ghosts and the neighbour list kept in HBM
+    (list built by mtp_build_neighbors_device, ghost update / force fold as device index maps) follow the
+    oracle-driven trajectory."""
+    import torch
+    from oracle.pyoracle import Oracle
+    from lammps_mtp_kokkos_amd.md import DeviceNVE
+    path = os.path.join(ROOT, "potentials", "W_L8.mtp")
+    pos0, box = mtpgen.bcc_lattice(4, 4, 8)
+    rng = np.random.default_rng(300)
+    vel0 = rng.normal(size=pos0.shape) * np.sqrt(KB * 300.0 / (MASS * MVV2E))
+    vel0 -= vel0.mean(0)
+    pot = capi.Potential(path)
+    ctx = capi.Context(pot, 0)
+    orc = Oracle(path)
+
+    def cpu_force(p):
+        s = periodic_system(p, box, None, 7.0)
+        r = orc.compute(s.x, s.types, s.ilist, s.first, s.neigh, eflag=1, vflag=0)
+        return s.fold_forces(r["f"]), r["energy"]
+
+    md = DeviceNVE(ctx, pos0.copy(), box, rc=pot.info.max_cutoff, mass=MASS, list_cutoff=7.0, every=3)
+    md.v.copy_(torch.from_numpy(vel0))
+    eg = []
+    for _ in range(10):
+        md.step(1e-3)
+        eg.append(md.total_energy())
+    pc, vc, ec = _run(cpu_force, pos0.copy(), box, vel0.copy(), 10, 1e-3)
+    assert md.builds >= 4                                   # re-neighboured on the device along the way
+    assert np.abs(md.x.cpu().numpy() - pc).max() < 1e-10 and np.abs(md.v.cpu().numpy() - vc).max() < 1e-9
+    assert np.abs(np.array(eg) - ec).max() < 1e-8
