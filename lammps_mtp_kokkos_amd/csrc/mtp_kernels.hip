@@ -43,11 +43,18 @@ namespace {
 #define MTP_PU 4   // times rows in flight per lane in the product passes
 #endif
 
-// The parameter block is read through the kernarg segment pointer (scalar loads from the constant cache) and the
-// pointer is made opaque at every phase boundary: the compiler then re-reads the few fields a phase needs instead
-// of carrying ~100 dwords of parameters in SGPRs across the whole atom loop (which spilled them into VGPR lanes:
-// a quarter of the per-atom VALU instructions were v_readlane / v_writelane).
+// The parameter block is read through the kernarg segment pointer (address space 4: scalar loads from the constant
+// cache that the compiler re-issues where a field is needed) instead of a by-value struct, which it kept in SGPRs
+// across the whole atom loop and spilled into VGPR lanes (a quarter of the static VALU instructions were
+// v_readlane / v_writelane, 255 VGPRs; now 229 and none).  Making the pointer opaque again at every phase boundary
+// (MTP_KP_FRESH) was measured 1 % slower.
 typedef const __attribute__((address_space(4))) MtpDevParams *KP;
+#ifdef MTP_EXP_SCALARS_LDS_ONLY   // timing experiment
+#define MTP_SCALARS_COND true
+#else
+#define MTP_SCALARS_COND kp->scalars_in_lds
+#endif
+#ifdef MTP_KP_FRESH
 static __device__ __forceinline__ KP kp_fresh()
 {
   KP k = (KP) __builtin_amdgcn_kernarg_segment_ptr();
@@ -55,6 +62,9 @@ static __device__ __forceinline__ KP kp_fresh()
   return k;
 }
 #define KP_FRESH() kp = kp_fresh()
+#else
+#define KP_FRESH() ((void) 0)
+#endif
 
 template <int PITCH> struct WaveLds {
   static constexpr int NT = PITCH - 2;
@@ -450,6 +460,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
     KP_FRESH();
     // ---- 1. compaction (the first NT survivors go straight into the tile arrays) --------
     int cnt = 0;
+    const int cj_last = kp->cj_cap - 1;
     for (int c0 = 0; c0 < jnum; c0 += 128) {
       // two list entries per lane; the loads of both are in flight together (clamped indices, no branches)
       int j2[2], jt2[2];
@@ -488,7 +499,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
         const unsigned long long m = __ballot(in);
         if (in) {
           const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-          if (pos < kp->cj_cap) w.cj[pos] = j;   // a list longer than the declared max_numneigh is reported below
+          w.cj[min(pos, cj_last)] = j;   // a list longer than the declared max_numneigh is reported below
           if (pos < NT) {
             const double r = sqrt(r2);
             w.nbx[pos] = dx;
@@ -581,7 +592,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
     if (GRADE) {
       double *crow = kp->cvec + (size_t) ii * kp->cpad + kp->Sp * kp->Sp * kp->Mu * kp->R;
       for (int k = lane; k < kp->Sp; k += 64) crow[k] = k == itype ? 1.0 : 0.0;
-      if (kp->scalars_in_lds)
+      if (MTP_SCALARS_COND)
         for (int k = lane; k < kp->S; k += 64) crow[kp->Sp + k] = w.M[bt.map[k]];
       else
         for (int k = lane; k < kp->S; k += 64) crow[kp->Sp + k] = w.M[kp->g_map[k]];
@@ -589,13 +600,13 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
     // ---- site energy (pair_mtp.cpp:204-212) ----------------------------------------------
     double e = 0.0;
     // (two code paths per table home, LDS blob or HBM/L2: no pointer selects between address spaces, see below)
-    if (kp->scalars_in_lds)
+    if (MTP_SCALARS_COND)
       for (int k = lane; k < kp->S; k += 64) e += bt.lin[k] * w.M[bt.map[k]];
     else
       for (int k = lane; k < kp->S; k += 64) e += kp->g_lin[k] * w.M[kp->g_map[k]];
     e = wave_sum(e) + kp->species_coeffs[itype];
     // ---- 4b. adjoints (pair_mtp.cpp:217-233) ----------------------------------------------
-    if (kp->scalars_in_lds)
+    if (MTP_SCALARS_COND)
       for (int k = lane; k < kp->nseed; k += 64) w.D[bt.seed_idx[k]] = bt.seed_val[k];
     else
       for (int k = lane; k < kp->nseed; k += 64) w.D[kp->g_seed_idx[k]] = kp->g_seed_val[k];
