@@ -316,6 +316,15 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     // The packed rows stay in HBM/L2 unless they are tiny: measured cost at level 16 is < 1 % (row
     // reads do not depend on data), and without them in every workgroup's LDS one more wavefront fits per CU.
     bb.rows_in_lds = rows8.size() * sizeof(MtpRow8) <= 1024;
+    {   // ... or when they fit next to 8 wavefronts' private regions anyway (measured 1.2 % faster at level 16);
+        // estimate with the usual list (<= 128 entries per row, 32-neighbour tile) -- plan() has the last word on
+        // the workgroup shape, this only decides where the rows live
+      const int A_ = pot->alpha_moment_count, P_ = pot->max_alpha_index_basic;
+      const size_t dbl = (size_t) 2 * pot->slot_count * 34 + std::max(3 * P_ * 34, A_ + std::max(std::max(A_, pot->coef_total), 16)) + 5 * 32;
+      const size_t wb = (dbl * 8 + (64 + 128) * 4 + 15) / 16 * 16;
+      const size_t others = 8192;   // the rest of the blob, generously
+      if (8 * wb + others + rows8.size() * sizeof(MtpRow8) <= 160 * 1024) bb.rows_in_lds = 1;
+    }
     if (const char *e = std::getenv("MTP_ROWS_LDS")) {   // tuning override (benchmarks only)
       if (std::atoi(e) != 0 && rows8.size() * sizeof(MtpRow8) <= 24 * 1024) bb.rows_in_lds = 1;
     }
