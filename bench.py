@@ -202,6 +202,24 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # LDS side of the dominant kernel (its actual bound): wave-level LDS instructions per launch from the committed
+    # rocprofv3 SQ counters of this configuration (profiles/r01_pmc_sq_counters.txt; not collected live), each moving
+    # at most 64 lanes x 8 B, against 128 B/clk/CU x 256 CUs x 2.4 GHz
+    lds_block = None
+    cpath = os.path.join(ROOT, "profiles", "r01_pmc_sq_counters.txt")
+    if os.path.exists(cpath) and args.workload == "w16" and world == 1 and args.cells == 32:
+        try:
+            cnt = {ln.split()[0]: float(ln.split()[1]) for ln in open(cpath) if ln[:1] not in "#\n" and len(ln.split()) == 2}
+            lds_bytes = cnt["SQ_INSTS_LDS"] * 64 * 8
+            peak = 128 * 256 * 2.4e9 / 1e12
+            lds_block = {"achieved": lds_bytes / (kernel_ms * 1e-3) / 1e12, "peak": peak, "unit": "TB/s",
+                         "frac": lds_bytes / (kernel_ms * 1e-3) / 1e12 / peak,
+                         "lds_wave_instructions_per_launch": cnt["SQ_INSTS_LDS"],
+                         "lds_unit_busy_frac_pmc": cnt.get("SQ_LDS_IDX_ACTIVE", 0.0) / 256 / (kernel_ms * 1e-3 * 2.4e9),
+                         "note": "upper bound on bytes (every LDS instruction counted as 64 lanes x 8 B); counters from "
+                                 "profiles/r01_pmc_sq_counters.txt, time measured live"}
+        except Exception:
+            lds_block = None
 
     # ---- CPU baseline: the oracle (a port of the reference CPU path), 1 thread, rank 0, N = 1 -----
     cpu = None
@@ -274,6 +292,7 @@ def main():
                          "kernel": "mtp_wave_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": bytes_alg,
                          "note": "fused kernel is fp64-VALU/LDS bound, not HBM bound (SURVEY.md 8d); "
                                  "fp64 fraction below uses the REFERENCE algorithm's flop count",
+                         "lds": lds_block,
                          "fp64_valu": {"achieved": flops_ref / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
                                        "unit": "TFLOP/s",
                                        "frac": flops_ref / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
