@@ -365,6 +365,8 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     bb.off_pack = put(pot->basic_pack.data(), pot->basic_pack.size() * sizeof(int32_t));
     bb.off_coef = put(pot->basic_tgt.data(), pot->basic_tgt.size() * sizeof(int32_t));
     bb.off_smu = put(pot->slot_mu.data(), pot->slot_mu.size() * sizeof(int32_t));
+    bb.off_fwd = put(pot->fwd_blocks.data(), pot->fwd_blocks.size() * sizeof(int32_t));
+    bb.nfb = pot->fwd_block_count;
     blob.resize((blob.size() + 15) / 16 * 16, 0);
     bb.blob_bytes = (int) blob.size();
     c->d_blob.upload(blob.data(), blob.size(), st);
@@ -428,6 +430,11 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     b.err_flag = c->d_err.ptr;
     b.stamps = c->d_stamps.ptr;
     int kl_ = 0, kb_ = 0;
+    if (mtp_pick_fwd_shape(pot->fwd_block_count, &kl_, &kb_) != 0) {
+      copy_err("more than 256 head x tail blocks of basic moments are not supported by this build", err, errlen);
+      delete c;
+      return MTP_ERR_LIMIT;
+    }
     if (mtp_pick_shape(pot->alpha_index_basic_count, &kl_, &kb_) != 0) {
       copy_err("alpha_index_basic_count above 640 is not supported by this build", err, errlen);
       delete c;

@@ -39,6 +39,8 @@ struct MtpDevParams {
   int off_map;             // int[S]
   int off_lin;             // double[S]
   int off_pack;            // int[B] slot | a<<8 | b<<12 | c<<16 | mu<<20
+  int off_fwd;             // int[nfb][8] head x tail blocks of the basic-moment pass (mtp_potential.hpp)
+  int nfb;                 // number of those blocks
   int off_smu;             // int[nslot] radial function index mu of each slot
   int off_coef;            // int2[B] scatter targets of each basic's adjoint: {tx | ty << 16, tz | fa << 16 | fb << 20 | fc << 24}
   int rows_in_lds;
@@ -78,8 +80,10 @@ struct MtpDevParams {
   float inv_mu;            // 1 / Mu
 };
 
-// lane-grid shape for B basics: KL k-lanes x KB basics per lane; -1 when B is too large
+// lane-grid shape of the candidate-vector kernel for B basics: KL k-lanes x KB basics per lane; -1 when B is too large
 int mtp_pick_shape(int B, int *KL, int *KB);
+// lane-grid shape of the force kernel's basic-moment pass: KL lanes x NB 3x3 blocks per lane; -1 beyond 256 blocks
+int mtp_pick_fwd_shape(int nblk, int *KL, int *NB);
 hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);
 hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st);
 // radial block of cvec from dbasic (grade calls, after the force kernel)

@@ -154,7 +154,7 @@ template <> struct Butterfly<1> {
 
 struct BlockTables {   // views into the workgroup-shared head of LDS
   const MtpRow8 *rows;
-  const int *level, *slot, *seed_idx, *map, *pack, *coef, *smu;
+  const int *level, *slot, *seed_idx, *map, *pack, *coef, *smu, *fwd;
   const double *radial, *seed_val, *lin;
 };
 

@@ -376,7 +376,7 @@ __device__ __forceinline__ void force_degree(KP kp, unsigned pcol, unsigned pcoe
   }
 }
 
-template <int KL, int KB, int PITCH, bool GRADE, int DEG>
+template <int KL, int NB, int PITCH, bool GRADE, int DEG>
 __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_arg)
 {
   constexpr int NT = PITCH - 2;          // neighbours per tile (32 or 16)
@@ -404,6 +404,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
   bt.pack = reinterpret_cast<const int *>(sh + kp->off_pack);
   bt.coef = reinterpret_cast<const int *>(sh + kp->off_coef);
   bt.smu = reinterpret_cast<const int *>(sh + kp->off_smu);
+  bt.fwd = reinterpret_cast<const int *>(sh + kp->off_fwd);
   const bool rows_lds = kp->rows_in_lds != 0;
 
   const int lane = threadIdx.x & 63;
@@ -416,25 +417,28 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
   const WaveLds<PITCH> w(lds + wave_off, lds0 + 8u * wave_off, kp);
   const int ns = kp->nslot, P = kp->P;
 
-  // per-lane descriptors of the basics this lane owns (k = kl + KL t): LDS row bases for
-  // this lane's neighbour column q; the partner row (dg, next power) is +PITCH
-  unsigned pg[KB], px[KB], py[KB], pz[KB];   // LDS byte addresses
-  bool kval[KB];
+  // Basic-moment pass in 3 x 3 register blocks (built on the host, mtp_potential.cpp): lane (q, kl) owns the blocks
+  // kl + KL t; a block is 3 heads (slot s, exponent a: head value g_s x^a) times 3 tails (b, c: tail value y^b z^c)
+  // with b + c = nu_s - a for all of them, i.e. nine basics from twelve table rows.  Per block: LDS byte addresses of
+  // the rows for this lane's neighbour column q.
+  unsigned hg[NB][3], hx[NB][3], ty[NB][3], tz[NB][3];
+  bool bval[NB];
 #pragma unroll
-  for (int t = 0; t < KB; t++) {
-    const int k = kl + KL * t;
-    kval[t] = k < kp->B;
-    const int pk = kval[t] ? bt.pack[k] : 0;
-    const int a = (pk >> 8) & 15, b = (pk >> 12) & 15, c = (pk >> 16) & 15;
-    // rows: g at slot (dg at ns + slot is read by the force phase); px/py/pz point at the row BELOW u^a
-    // (the power itself is +PITCH)
-    pg[t] = w.addr(w.tab + (size_t) (pk & 255) * PITCH + q);
-    px[t] = w.addr(w.tab + (size_t) (2 * ns + a - 1) * PITCH + q);
-    py[t] = w.addr(w.tab + (size_t) (2 * ns + P + b - 1) * PITCH + q);
-    pz[t] = w.addr(w.tab + (size_t) (2 * ns + 2 * P + c - 1) * PITCH + q);
-    // one finished address per register: stops the optimiser from re-splitting them into
-    // base + row offset (which costs a v_add per LDS read in the inner loops)
-    asm volatile("" : "+v"(pg[t]), "+v"(px[t]), "+v"(py[t]), "+v"(pz[t]));
+  for (int t = 0; t < NB; t++) {
+    const int blk = kl + KL * t;
+    bval[t] = blk < kp->nfb;
+    const int *bd = bt.fwd + 8 * (bval[t] ? blk : 0);
+    const unsigned w0 = (unsigned) bd[0], w1 = (unsigned) bd[1], w2 = (unsigned) bd[2];
+#pragma unroll
+    for (int h = 0; h < 3; h++) {
+      hg[t][h] = w.addr(w.tab + (size_t) ((w0 >> (8 * h)) & 255u) * PITCH + q);
+      hx[t][h] = w.addr(w.tab + (size_t) (2 * ns + ((w1 >> (4 * h)) & 15u)) * PITCH + q);
+      ty[t][h] = w.addr(w.tab + (size_t) (2 * ns + P + ((w1 >> (12 + 4 * h)) & 15u)) * PITCH + q);
+      tz[t][h] = w.addr(w.tab + (size_t) (2 * ns + 2 * P + ((w2 >> (4 * h)) & 15u)) * PITCH + q);
+      // one finished address per register: stops the optimiser from re-splitting them into
+      // base + row offset (which costs a v_add per LDS read in the inner loops)
+      asm volatile("" : "+v"(hg[t][h]), "+v"(hx[t][h]), "+v"(ty[t][h]), "+v"(tz[t][h]));
+    }
   }
 
   double tally = 0.0;   // lane 9: energy, lanes 3..8: virial components of this wave's atoms
@@ -535,9 +539,11 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
     STAMP(1);   // compaction
     KP_FRESH();
     // ---- 2+3. tiles: tables, then basic moments in registers ------------------------------
-    double acc[KB];
+    double acc[NB][9];
 #pragma unroll
-    for (int t = 0; t < KB; t++) acc[t] = 0.0;
+    for (int t = 0; t < NB; t++)
+#pragma unroll
+      for (int e = 0; e < 9; e++) acc[t][e] = 0.0;
     const int ntiles = (cnt + NT - 1) / NT;
     for (int tile = 0; tile < ntiles; tile++) {
       const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
@@ -547,21 +553,31 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
 #pragma unroll
       for (int m = 0; m < NPG; m++) {
         if (m * NG < ntp) {
-          // all 4*KB reads of this column issue back to back (one LDS latency), then the FMAs;
-          // the barriers keep the scheduler from either splitting the burst or hoisting every
-          // column's reads (register blow-up)
-          double G[KB], X[KB], Y[KB], Z[KB];
+          // the 12 reads of a block issue back to back (one LDS latency), then 6 products and 9 FMAs; the barriers
+          // keep the scheduler from either splitting the burst or hoisting every column's reads (register blow-up)
 #pragma unroll
-          for (int t = 0; t < KB; t++) {
-            G[t] = lds_ld(pg[t], m * NG);
-            X[t] = lds_ld(px[t], PITCH + m * NG);
-            Y[t] = lds_ld(py[t], PITCH + m * NG);
-            Z[t] = lds_ld(pz[t], PITCH + m * NG);
+          for (int t = 0; t < NB; t++) {
+            double G[3], X[3], Y[3], Z[3];
+#pragma unroll
+            for (int h = 0; h < 3; h++) {
+              G[h] = lds_ld(hg[t][h], m * NG);
+              X[h] = lds_ld(hx[t][h], m * NG);
+              Y[h] = lds_ld(ty[t][h], m * NG);
+              Z[h] = lds_ld(tz[t][h], m * NG);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double hd[3], tl[3];
+#pragma unroll
+            for (int h = 0; h < 3; h++) {
+              hd[h] = G[h] * X[h];
+              tl[h] = Y[h] * Z[h];
+            }
+#pragma unroll
+            for (int h = 0; h < 3; h++)
+#pragma unroll
+              for (int u = 0; u < 3; u++) acc[t][3 * h + u] = fma(hd[h], tl[u], acc[t][3 * h + u]);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int t = 0; t < KB; t++) acc[t] += G[t] * (X[t] * (Y[t] * Z[t]));
-          __builtin_amdgcn_sched_barrier(0);
         }
       }
       if (ntiles > 1) wave_fence();
@@ -570,16 +586,26 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
     KP_FRESH();
     // sum over the neighbour groups, then moments + adjoints into LDS
 #pragma unroll
-    for (int t = 0; t < KB; t++) {
-      if (NG >= 4) acc[t] = pair_sum16(acc[t]);   // KL = 16: groups differ in lane bits 4 and 5
-      if (NG >= 2) acc[t] = pair_sum32(acc[t]);
-    }
+    for (int t = 0; t < NB; t++)
+#pragma unroll
+      for (int e = 0; e < 9; e++) {
+        if (NG >= 4) acc[t][e] = pair_sum16(acc[t][e]);   // KL = 16: groups differ in lane bits 4 and 5
+        if (NG >= 2) acc[t][e] = pair_sum32(acc[t][e]);
+      }
     for (int m = kp->B + lane; m < kp->A; m += 64) w.M[m] = 0.0;
     for (int m = lane; m < kp->A; m += 64) w.D[m] = 0.0;
     if (q == 0) {
 #pragma unroll
-      for (int t = 0; t < KB; t++)
-        if (kval[t]) w.M[kl + KL * t] = acc[t];
+      for (int t = 0; t < NB; t++)
+        if (bval[t]) {
+          // nine int16 basic indices of the block (-1: no such basic), 20 bytes after the three descriptor words
+          const short *kk = reinterpret_cast<const short *>(bt.fwd + 8 * (kl + KL * t) + 3);
+#pragma unroll
+          for (int e = 0; e < 9; e++) {
+            const int k = kk[e];
+            if (k >= 0) w.M[k] = acc[t][e];
+          }
+        }
     }
     wave_fence();
 
@@ -625,27 +651,27 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
       for (int k = lane; k < kp->coef_total; k += 64) w.M[k] = 0.0;
       wave_fence();
     }
-    {
-      constexpr int ROUNDS = (KL * KB + 63) / 64;
+    for (int k0 = 0; k0 < (GRADE && kp->dbasic ? max(kp->dpad, kp->B) : kp->B); k0 += 192) {
+      constexpr int ROUNDS = 3;   // 192 basics per trip: all reads first, one LDS round trip
       double dd[ROUNDS];
       int2 tg[ROUNDS];
 #pragma unroll
-      for (int u = 0; u < ROUNDS; u++) {   // all reads first: one LDS round trip
-        const int k = lane + 64 * u, kc = min(k, kp->B - 1);
+      for (int u = 0; u < ROUNDS; u++) {
+        const int k = k0 + lane + 64 * u, kc = min(k, kp->B - 1);
         dd[u] = w.D[kc];
         tg[u] = reinterpret_cast<const int2 *>(bt.coef)[kc];
       }
 #pragma unroll
       for (int u = 0; u < ROUNDS; u++) {
-        const int k = lane + 64 * u;
+        const int k = k0 + lane + 64 * u;
         const bool ok = k < kp->B;
-        if (GRADE && kp->dbasic && k < KL * KB) kp->dbasic[(size_t) ii * kp->dpad + k] = ok ? dd[u] : 0.0;   // read back by mtp_cvec_kernel
+        if (GRADE && kp->dbasic && k < kp->dpad) kp->dbasic[(size_t) ii * kp->dpad + k] = ok ? dd[u] : 0.0;   // read back by mtp_cvec_kernel
         if (ok) {
           const unsigned t0 = (unsigned) tg[u].x, t1 = (unsigned) tg[u].y;
-          const unsigned tx = t0 & 0xffffu, ty = t0 >> 16, tz = t1 & 0xffffu;
+          const unsigned tx = t0 & 0xffffu, ty_ = t0 >> 16, tz_ = t1 & 0xffffu;
           if (tx != 0xffffu) w.M[tx] = dd[u] * (double) ((t1 >> 16) & 15u);
-          if (ty != 0xffffu) w.M[ty] = dd[u] * (double) ((t1 >> 20) & 15u);
-          if (tz != 0xffffu) w.M[tz] = dd[u] * (double) ((t1 >> 24) & 15u);
+          if (ty_ != 0xffffu) w.M[ty_] = dd[u] * (double) ((t1 >> 20) & 15u);
+          if (tz_ != 0xffffu) w.M[tz_] = dd[u] * (double) ((t1 >> 24) & 15u);
         }
       }
     }
@@ -966,41 +992,41 @@ __global__ void __launch_bounds__(256) mtp_colsum_kernel(const double *__restric
   unsafeAtomicAdd(&coeff_ders[c], s);
 }
 
-template <int KL, int KB, int PITCH, bool GRADE, int DEG>
+template <int KL, int NB, int PITCH, bool GRADE, int DEG>
 hipError_t launch_one(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
 {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mtp_wave_kernel<KL, KB, PITCH, GRADE, DEG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mtp_wave_kernel<KL, NB, PITCH, GRADE, DEG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((mtp_wave_kernel<KL, KB, PITCH, GRADE, DEG>), dim3(grid), dim3(64 * wpb), lds, st, p);
+  hipLaunchKernelGGL((mtp_wave_kernel<KL, NB, PITCH, GRADE, DEG>), dim3(grid), dim3(64 * wpb), lds, st, p);
   return hipGetLastError();
 }
 
-template <int KL, int KB, int DEG> hipError_t launch_grade(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
+template <int KL, int NB, int DEG> hipError_t launch_grade(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
 {
   // only the 32-neighbour tile (pitch 34) is instantiated; the grade variant is its own instantiation so the
   // force-only kernel keeps its register budget
-  return p.grade_flag ? launch_one<KL, KB, 34, true, DEG>(p, grid, wpb, lds, st)
-                      : launch_one<KL, KB, 34, false, DEG>(p, grid, wpb, lds, st);
+  return p.grade_flag ? launch_one<KL, NB, 34, true, DEG>(p, grid, wpb, lds, st)
+                      : launch_one<KL, NB, 34, false, DEG>(p, grid, wpb, lds, st);
 }
 
 // DEG = highest tensor rank the unrolled force phase covers (monomials up to degree DEG-1 in registers):
-// narrow lane grids (B <= 160) come with ranks <= 6 in the MLIP level tables, wide ones with ranks <= 8;
+// narrow lane grids come with ranks <= 6 in the MLIP level tables, wide ones with ranks <= 8;
 // DEG = 11 is the general instantiation (the loader caps the rank at 11).
-template <int KL, int KB> hipError_t launch_pitch(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
+template <int KL, int NB> hipError_t launch_pitch(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
 {
-  constexpr int DLOW = KL == 16 ? 6 : 8;
-  if (p.P - 1 <= DLOW) return launch_grade<KL, KB, DLOW>(p, grid, wpb, lds, st);
-  return launch_grade<KL, KB, 11>(p, grid, wpb, lds, st);
+  constexpr int DLOW = KL <= 32 ? 6 : 8;
+  if (p.P - 1 <= DLOW) return launch_grade<KL, NB, DLOW>(p, grid, wpb, lds, st);
+  return launch_grade<KL, NB, 11>(p, grid, wpb, lds, st);
 }
 
 }   // namespace
 
-// Supported (KL, KB) shapes; mtp_pick_shape() is the single source of truth for the host.
+// Lane grids of the candidate-vector kernel (KL k-lanes x KB basics per lane); also sizes dbasic rows.
 int mtp_pick_shape(int B, int *KL, int *KB)
 {
   static const int kb16[] = {2, 3, 5, 7, 9, 10}, kbw[] = {6, 7, 8, 10};
@@ -1020,26 +1046,37 @@ int mtp_pick_shape(int B, int *KL, int *KB)
   return -1;
 }
 
+// Lane grids of the force kernel's basic-moment pass: KL block lanes x NB 3x3 blocks per lane (KL * NB >= blocks);
+// mtp_pick_fwd_shape() is the single source of truth for the host.
+int mtp_pick_fwd_shape(int nblk, int *KL, int *NB)
+{
+  for (int kl : {16, 32, 64})
+    if (nblk <= kl) {
+      *KL = kl;
+      *NB = 1;
+      return 0;
+    }
+  for (int nb : {2, 3, 4})
+    if (nblk <= 64 * nb) {
+      *KL = 64;
+      *NB = nb;
+      return 0;
+    }
+  return -1;
+}
+
 hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
 {
-  int KL = 0, KB = 0;
-  if (mtp_pick_shape(p.B, &KL, &KB) != 0 || p.NT != 32) return hipErrorInvalidValue;
-#define MTP_CASE(kl, kb) \
-  if (KL == kl && KB == kb) return launch_pitch<kl, kb>(p, grid, wpb, lds, st);
-  MTP_CASE(16, 2)
-  MTP_CASE(16, 3)
-  MTP_CASE(16, 5)
-  MTP_CASE(16, 7)
-  MTP_CASE(16, 9)
-  MTP_CASE(16, 10)
-  MTP_CASE(32, 6)
-  MTP_CASE(32, 7)
-  MTP_CASE(32, 8)
-  MTP_CASE(32, 10)
-  MTP_CASE(64, 6)
-  MTP_CASE(64, 7)
-  MTP_CASE(64, 8)
-  MTP_CASE(64, 10)
+  int KL = 0, NB = 0;
+  if (mtp_pick_fwd_shape(p.nfb, &KL, &NB) != 0 || p.NT != 32) return hipErrorInvalidValue;
+#define MTP_CASE(kl, nb) \
+  if (KL == kl && NB == nb) return launch_pitch<kl, nb>(p, grid, wpb, lds, st);
+  MTP_CASE(16, 1)
+  MTP_CASE(32, 1)
+  MTP_CASE(64, 1)
+  MTP_CASE(64, 2)
+  MTP_CASE(64, 3)
+  MTP_CASE(64, 4)
 #undef MTP_CASE
   return hipErrorInvalidValue;
 }

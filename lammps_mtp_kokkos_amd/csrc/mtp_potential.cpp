@@ -526,6 +526,60 @@ int mtp_potential::finalize(std::string &err)
       basic_tgt[2 * (size_t) i] = (int32_t) (tx | (ty << 16));
       basic_tgt[2 * (size_t) i + 1] = (int32_t) (tz | (fa << 16) | ((uint32_t) b << 20) | ((uint32_t) c << 24));
     }
+    // head x tail blocks of the basic-moment pass
+    {
+      std::vector<int> basic_of((size_t) slot_count * 16 * 16 * 16, -1);   // (slot, a, b, c) -> k
+      for (int i = 0; i < B; i++) {
+        const int32_t *q = &alpha_index_basic[4 * (size_t) i];
+        basic_of[(((size_t) (basic_pack[i] & 255) * 16 + q[1]) * 16 + q[2]) * 16 + q[3]] = i;
+      }
+      std::vector<int> slot_nu((size_t) slot_count, 0);
+      for (int nu = 0; nu < P; nu++)
+        for (int sidx = deg_first[nu]; sidx < deg_first[nu + 1]; sidx++) slot_nu[sidx] = nu;
+      fwd_blocks.clear();
+      fwd_block_count = 0;
+      std::vector<int> covered((size_t) B, 0);
+      for (int j = 0; j < P; j++) {
+        std::vector<std::pair<int, int>> heads, tails;   // (slot, a), (b, c)
+        for (int sidx = 0; sidx < slot_count; sidx++)
+          if (slot_nu[sidx] >= j) heads.push_back({sidx, slot_nu[sidx] - j});
+        for (int c = 0; c <= j; c++) tails.push_back({j - c, c});
+        for (size_t h0 = 0; h0 < heads.size(); h0 += 3)
+          for (size_t t0 = 0; t0 < tails.size(); t0 += 3) {
+            int32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int16_t kk[10];
+            for (int e = 0; e < 10; e++) kk[e] = -1;
+            bool any = false;
+            for (int h = 0; h < 3 && h0 + h < heads.size(); h++) {
+              w[0] |= heads[h0 + h].first << (8 * h);
+              w[1] |= heads[h0 + h].second << (4 * h);
+            }
+            for (int t = 0; t < 3 && t0 + t < tails.size(); t++) {
+              w[1] |= tails[t0 + t].first << (12 + 4 * t);
+              w[2] |= tails[t0 + t].second << (4 * t);
+            }
+            for (int h = 0; h < 3 && h0 + h < heads.size(); h++)
+              for (int t = 0; t < 3 && t0 + t < tails.size(); t++) {
+                const int k = basic_of[(((size_t) heads[h0 + h].first * 16 + heads[h0 + h].second) * 16 +
+                                        tails[t0 + t].first) * 16 + tails[t0 + t].second];
+                if (k >= 0) {
+                  kk[3 * h + t] = (int16_t) k;
+                  covered[k]++;
+                  any = true;
+                }
+              }
+            if (!any) continue;
+            std::memcpy(&w[3], kk, sizeof(int16_t) * 10);
+            fwd_blocks.insert(fwd_blocks.end(), w, w + 8);
+            fwd_block_count++;
+          }
+      }
+      for (int i = 0; i < B; i++)
+        if (covered[i] != 1) {
+          err = "internal: basic moment not covered exactly once by the head x tail blocks";
+          return MTP_ERR_TABLE;
+        }
+    }
     coef_dense = 1;
     for (int t = 0; t < coef_total; t++) {
       if (hits[t] > 1) {

@@ -46,6 +46,12 @@ struct mtp_potential {
   // receive fa*D, fb*D, fc*D; coef_dense = every entry has a source (no zero fill needed)
   std::vector<int32_t> basic_tgt;
   int coef_dense = 0;
+  // Basic-moment pass in 3 x 3 register blocks: a basic (slot s; a, b, c) is head (s, a) x tail (b, c) with
+  // g_s x^a as the head value and y^b z^c as the tail value; all heads of a block share j = nu_s - a = b + c.
+  // 8 ints per block: {s0 | s1<<8 | s2<<16, a0 | a1<<4 | a2<<8 | b0<<12 | b1<<16 | b2<<20, c0 | c1<<4 | c2<<8,
+  // then nine int16 basic indices (head-major, -1 = no such basic) in 4.5 ints, padded}
+  std::vector<int32_t> fwd_blocks;
+  int fwd_block_count = 0;
   // per basic: slot | a<<8 | b<<12 | c<<16 | mu<<20 (what a lane needs per k)
   std::vector<int32_t> basic_pack;
   // adjoint seeds: D[idx] = val (last mapping entry wins, pair_mtp.cpp:217-218)
