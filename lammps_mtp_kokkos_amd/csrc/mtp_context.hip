@@ -690,6 +690,10 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
   p.eflag = eflag;
   p.vflag = vflag;
   p.grade_flag = grade_flag ? 1 : 0;
+  {
+    static const bool xcd_on = [] { const char *e = std::getenv("MTP_XCD_MAP"); return !e || std::atoi(e) != 0; }();
+    p.xcd_map = xcd_on && c->inum >= 8 * 64 ? 1 : 0;   // tuning override: MTP_XCD_MAP=0
+  }
   const mtp_context::LaunchPlan &L = c->lp[0];
   p.tab_rows = L.tab_rows;
   p.m_doubles = L.m_doubles;

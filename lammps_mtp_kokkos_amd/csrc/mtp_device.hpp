@@ -68,6 +68,7 @@ struct MtpDevParams {
   int *err_flag;
   unsigned long long *stamps;   // [16] diagnostic build only (MTP_STAMPS), else unused
   int eflag, vflag, grade_flag;
+  int xcd_map;             // contiguous eighths of ilist per XCD (workgroup b belongs to XCD b % 8)
   int grade_fused;         // grade calls: the force kernel also writes the radial block of cvec (R = 8, Mu <= 4, Sp <= 2)
   // launch geometry
   int NT;                  // neighbours per LDS tile: 32 or 16 (table row pitch = NT + 2 doubles)

@@ -447,7 +447,22 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
   unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #endif
 
-  for (int ii = blockIdx.x * wpb + wave; ii < kp->inum; ii += gridDim.x * wpb) {
+  // XCD-aware atom map: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b works
+  // for XCD b % 8; giving every XCD one contiguous eighth of ilist (callers keep atoms roughly in spatial order:
+  // LAMMPS sorts them, the bench lattice is cell-major) keeps the position gathers and the force atomics of a slab in
+  // ONE L2 instead of spreading every slab over all eight.
+  int ii_beg, ii_end, ii_step;
+  if (kp->xcd_map && (gridDim.x & 7) == 0) {
+    const int chunk = (kp->inum + 7) >> 3, xcd = blockIdx.x & 7;
+    ii_beg = xcd * chunk + (blockIdx.x >> 3) * wpb + wave;
+    ii_end = min(kp->inum, (xcd + 1) * chunk);
+    ii_step = (gridDim.x >> 3) * wpb;
+  } else {
+    ii_beg = blockIdx.x * wpb + wave;
+    ii_end = kp->inum;
+    ii_step = gridDim.x * wpb;
+  }
+  for (int ii = ii_beg; ii < ii_end; ii += ii_step) {
     // ii is wave-uniform, so is everything loaded through it: keep it in SGPRs
     const int i = __builtin_amdgcn_readfirstlane(kp->ilist[ii]);
     const int itype = __builtin_amdgcn_readfirstlane(kp->type[i] - 1);
