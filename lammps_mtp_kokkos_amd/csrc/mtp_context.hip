@@ -349,14 +349,14 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     if (bb.scalars_in_lds) {
       bb.off_seed_idx = put(pot->seed_idx.data(), pot->seed_idx.size() * sizeof(int32_t));
       bb.off_seed_val = put(pot->seed_val.data(), pot->seed_val.size() * sizeof(double));
-      bb.off_map = put(pot->alpha_moment_mapping.data(), pot->alpha_moment_mapping.size() * sizeof(int32_t));
+      bb.off_map = put(pot->mapping_lds.data(), pot->mapping_lds.size() * sizeof(int32_t));
       bb.off_lin = put(pot->linear_coeffs.data(), pot->linear_coeffs.size() * sizeof(double));
     } else {
       bb.off_seed_idx = bb.off_seed_val = bb.off_map = bb.off_lin = 0;
     }
     c->d_seed_idx.upload(pot->seed_idx, st);
     c->d_seed_val.upload(pot->seed_val, st);
-    c->d_map.upload(pot->alpha_moment_mapping, st);
+    c->d_map.upload(pot->mapping_lds, st);
     c->d_lin.upload(pot->linear_coeffs, st);
     bb.g_seed_idx = c->d_seed_idx.ptr;
     bb.g_seed_val = c->d_seed_val.ptr;

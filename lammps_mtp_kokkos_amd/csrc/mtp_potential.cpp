@@ -463,6 +463,78 @@ int mtp_potential::finalize(std::string &err)
         seed_val.push_back(linear_coeffs[last[m]]);
       }
   }
+  // LDS placement of the product moments: the product passes touch M[a0], M[a1], M[a3] / D[...] of 32
+  // consecutive rows per half-wavefront access, and moments that share an 8-byte bank (index mod 32) but not an
+  // address serialise.  The row order is fixed by now; renumber the moments [B, A) (basics keep their numbers: the
+  // basic-moment pass and the coefficient blocks address them by k) by pairwise swaps that lower the number of
+  // same-bank distinct moments per access.  Deterministic (fixed-seed LCG).  moment_perm[old] = new.
+  moment_perm.resize((size_t) A);
+  for (int m = 0; m < A; m++) moment_perm[m] = m;
+  if (A - B >= 2 && !rows_by_level.empty()) {
+    const int ngroups = (int) rows_by_level.size() / 32;
+    const int weight[3] = {3, 3, 2};   // a0, a1: two reads + one atomic each; a3: one read + one atomic
+    std::vector<std::vector<int>> occ((size_t) A);            // moment -> (group * 3 + stream) it appears in (distinct)
+    std::vector<uint8_t> hist((size_t) ngroups * 3 * 32, 0);  // distinct moments per bank of each access
+    for (int g = 0; g < ngroups; g++)
+      for (int st = 0; st < 3; st++) {
+        std::vector<int> seen;
+        for (int r = 32 * g; r < 32 * g + 32; r++) {
+          const MtpRow &row = rows_by_level[(size_t) r];
+          const int m = st == 0 ? row.a0 : (st == 1 ? row.a1 : row.a3);
+          if (std::find(seen.begin(), seen.end(), m) == seen.end()) {
+            seen.push_back(m);
+            occ[(size_t) m].push_back(g * 3 + st);
+            hist[((size_t) g * 3 + st) * 32 + (m & 31)]++;
+          }
+        }
+      }
+    auto pen = [](int n) { return n > 1 ? n - 1 : 0; };
+    std::vector<int> bank((size_t) A);
+    for (int m = 0; m < A; m++) bank[m] = m & 31;
+    auto move_delta = [&](int m, int from, int to, int other) {   // cost change of moving m between banks
+      int d = 0;
+      for (int gs : occ[(size_t) m]) {
+        if (std::binary_search(occ[(size_t) other].begin(), occ[(size_t) other].end(), gs)) continue;   // both swap: no change
+        const uint8_t *h = &hist[(size_t) gs * 32];
+        d += weight[gs % 3] * (pen(h[from] - 1) + pen(h[to] + 1) - pen(h[from]) - pen(h[to]));
+      }
+      return d;
+    };
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() {
+      rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+      return (uint32_t) (rng >> 33);
+    };
+    const int movable = A - B;
+    const long long trials = std::min<long long>(400ll * movable, 2000000ll);
+    for (long long t = 0; t < trials; t++) {
+      const int m1 = B + (int) (next() % (uint32_t) movable), m2 = B + (int) (next() % (uint32_t) movable);
+      const int b1 = bank[m1], b2 = bank[m2];
+      if (b1 == b2) continue;
+      if (move_delta(m1, b1, b2, m2) + move_delta(m2, b2, b1, m1) >= 0) continue;
+      for (int gs : occ[(size_t) m1])
+        if (!std::binary_search(occ[(size_t) m2].begin(), occ[(size_t) m2].end(), gs)) {
+          hist[(size_t) gs * 32 + b1]--;
+          hist[(size_t) gs * 32 + b2]++;
+        }
+      for (int gs : occ[(size_t) m2])
+        if (!std::binary_search(occ[(size_t) m1].begin(), occ[(size_t) m1].end(), gs)) {
+          hist[(size_t) gs * 32 + b2]--;
+          hist[(size_t) gs * 32 + b1]++;
+        }
+      std::swap(bank[m1], bank[m2]);
+      std::swap(moment_perm[m1], moment_perm[m2]);
+    }
+    for (MtpRow &row : rows_by_level) {
+      row.a0 = moment_perm[row.a0];
+      row.a1 = moment_perm[row.a1];
+      row.a3 = moment_perm[row.a3];
+    }
+    for (int32_t &m : seed_idx) m = moment_perm[m];
+  }
+  mapping_lds.resize((size_t) S);
+  for (int i = 0; i < S; i++) mapping_lds[i] = moment_perm[alpha_moment_mapping[i]];
+
   // radial slots = distinct (mu, nu) of the basics, numbered by tensor rank nu, then mu
   slot_of.assign((size_t) Mu * P, -1);
   for (int i = 0; i < B; i++) {

@@ -33,6 +33,10 @@ struct mtp_potential {
   // times rows stably sorted by dependency level; level_offset[l]..level_offset[l+1]
   std::vector<MtpRow> rows_by_level;
   std::vector<int32_t> level_offset;
+  // LDS numbering of the moments (moment_perm[file index] = LDS index; identity on the basics) chosen to spread
+  // the product passes over the LDS banks; rows_by_level and seed_idx are already in LDS numbering,
+  // mapping_lds = alpha_moment_mapping in LDS numbering
+  std::vector<int32_t> moment_perm, mapping_lds;
   // distinct (mu, nu) pairs used by the basics -> slot; slot_of[mu*P+nu] or -1
   std::vector<int32_t> slot_of;
   int slot_count = 0;
