@@ -123,8 +123,8 @@ void mtp_context::plan()
     L.m_doubles = std::max(std::max(A, p.coef_total), 16);   // moments, later the derivative-polynomial coefficients
     const int d_doubles = A;
     // coordinate-power rows and moments/adjoints share one overlay (never live together)
-    L.ov_doubles = std::max(3 * P * (nt + 2), d_doubles + L.m_doubles);
-    const size_t dbl = (size_t) 2 * p.slot_count * (nt + 2) + L.ov_doubles + 5 * (size_t) nt;
+    L.ov_doubles = std::max(3 * P * MTP_PITCH, d_doubles + L.m_doubles);
+    const size_t dbl = (size_t) 2 * p.slot_count * MTP_PITCH + L.ov_doubles + 5 * (size_t) nt;
     const size_t ints = (size_t) 2 * nt + cap;
     const size_t wb = (dbl * 8 + ints * 4 + 15) / 16 * 16;
     // waves per CU for w waves per workgroup; registers allow 8 (2 per SIMD)
@@ -320,7 +320,7 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
         // estimate with the usual list (<= 128 entries per row, 32-neighbour tile) -- plan() has the last word on
         // the workgroup shape, this only decides where the rows live
       const int A_ = pot->alpha_moment_count, P_ = pot->max_alpha_index_basic;
-      const size_t dbl = (size_t) 2 * pot->slot_count * 34 + std::max(3 * P_ * 34, A_ + std::max(std::max(A_, pot->coef_total), 16)) + 5 * 32;
+      const size_t dbl = (size_t) 2 * pot->slot_count * MTP_PITCH + std::max(3 * P_ * MTP_PITCH, A_ + std::max(std::max(A_, pot->coef_total), 16)) + 5 * 32;
       const size_t wb = (dbl * 8 + (64 + 128) * 4 + 15) / 16 * 16;
       const size_t others = 8192;   // the rest of the blob, generously
       if (8 * wb + others + rows8.size() * sizeof(MtpRow8) <= 160 * 1024) bb.rows_in_lds = 1;

@@ -8,6 +8,7 @@
 
 #define MTP_EV_SLOTS 1024   // per-wave energy/virial tally slots (8 doubles each)
 #define MTP_MAX_WPB 8       // wavefronts per workgroup (512 threads)
+#define MTP_PITCH 33        // doubles per row of the per-wavefront LDS tables (32 neighbour columns + 1: odd pitch)
 #define MTP_PSTRIDE 12      // slot ids per mu in the LDS blob (nu = 0..11, -1 padded)
 
 // A times row packed in 8 bytes: lo = a0 | a1 << 16, hi = a3 | (mult & 0xffff) << 16
@@ -71,9 +72,9 @@ struct MtpDevParams {
   int xcd_map;             // contiguous eighths of ilist per XCD (workgroup b belongs to XCD b % 8)
   int grade_fused;         // grade calls: the force kernel also writes the radial block of cvec (R = 8, Mu <= 4, Sp <= 2)
   // launch geometry
-  int NT;                  // neighbours per LDS tile: 32 or 16 (table row pitch = NT + 2 doubles)
+  int NT;                  // neighbours per LDS tile: 32 (table row pitch MTP_PITCH doubles)
   int tab_rows;            // table rows = 2*nslot + 3*P (candidate-vector kernel: 4*P + R)
-  int ov_doubles;          // force kernel: doubles of the overlay = max(3*P*(NT+2), m_doubles + d_doubles)
+  int ov_doubles;          // force kernel: doubles of the overlay = max(3*P*MTP_PITCH, m_doubles + d_doubles)
   int cj_cap;              // capacity of the compacted id list
   int wave_doubles;        // LDS doubles per wavefront
   int m_doubles;           // doubles of the moment region = max(A, coef_total, 16)

@@ -67,7 +67,8 @@ static __device__ __forceinline__ KP kp_fresh()
 #endif
 
 template <int PITCH> struct WaveLds {
-  static constexpr int NT = PITCH - 2;
+  static constexpr int NT = 32;   // neighbours per tile; the row pitch (33 doubles: odd, so the 32 lanes of a half-wavefront
+                                  // reading 32 different rows of one column hit 32 different 8-byte banks) is the template parameter
   double *M, *D, *tab, *nbx, *nby, *nbz, *nbr, *nbi;
   int *nbj, *nbjt, *cj;
   unsigned m_addr;   // LDS byte address of M
@@ -379,7 +380,7 @@ __device__ __forceinline__ void force_degree(KP kp, unsigned pcol, unsigned pcoe
 template <int KL, int NB, int PITCH, bool GRADE, int DEG>
 __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_arg)
 {
-  constexpr int NT = PITCH - 2;          // neighbours per tile (32 or 16)
+  constexpr int NT = 32;                 // neighbours per tile
   constexpr int NG = 64 / KL;            // neighbour groups in the wavefront
   constexpr int NPG = NT / NG;           // neighbours per group per tile
   static_assert(NT == 32, "the force phase maps lanes to (32 neighbours) x (2 halves)");
@@ -1023,10 +1024,10 @@ hipError_t launch_one(const MtpDevParams &p, int grid, int wpb, size_t lds, hipS
 
 template <int KL, int NB, int DEG> hipError_t launch_grade(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
 {
-  // only the 32-neighbour tile (pitch 34) is instantiated; the grade variant is its own instantiation so the
+  // only the 32-neighbour tile (pitch MTP_PITCH) is instantiated; the grade variant is its own instantiation so the
   // force-only kernel keeps its register budget
-  return p.grade_flag ? launch_one<KL, NB, 34, true, DEG>(p, grid, wpb, lds, st)
-                      : launch_one<KL, NB, 34, false, DEG>(p, grid, wpb, lds, st);
+  return p.grade_flag ? launch_one<KL, NB, MTP_PITCH, true, DEG>(p, grid, wpb, lds, st)
+                      : launch_one<KL, NB, MTP_PITCH, false, DEG>(p, grid, wpb, lds, st);
 }
 
 // DEG = highest tensor rank the unrolled force phase covers (monomials up to degree DEG-1 in registers):
