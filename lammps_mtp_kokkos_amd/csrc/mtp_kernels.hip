@@ -335,11 +335,13 @@ __device__ __forceinline__ void force_degree(KP kp, unsigned pcol, unsigned pcoe
           const double G = poly_eval<C>(ca, m);
           UA = fma(g, G, UA);
           VA = fma(dg * inv_nu, G, VA);
-          if (GRADE) {
-            const int mu = smu[s0 + it];
+          if (GRADE) {   // the slot, hence mu, is wave-uniform in this pass: scalar branches, one add
+            const int mu = __builtin_amdgcn_readfirstlane(smu[s0 + it]);
             const double val = G * wa;
-#pragma unroll
-            for (int v = 0; v < 4; v++) W[v] += mu == v ? val : 0.0;
+            if (mu == 0) W[0] += val;
+            else if (mu == 1) W[1] += val;
+            else if (mu == 2) W[2] += val;
+            else W[3] += val;
           }
           ca += 8u * 3 * C;
           cg += 8u * PITCH;
