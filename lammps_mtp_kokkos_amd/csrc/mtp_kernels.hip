@@ -14,11 +14,11 @@
 //                   g[mu,nu](n) = f_mu(r)/r^nu and dg/dr (Chebyshev recurrence + radial
 //                   contraction, mtp_rb_chevbyshev_basis.cpp:29-54, pair_mtp.cpp:139-166)
 //                   and the coordinate powers x^p (pair_mtp.cpp:133-136)
-//   3. basic moments the wavefront is NG neighbour groups x KL k-lanes: lane (q, kl) owns the
-//                   basics k = kl + KL t and the neighbours n = q + NG m, and accumulates
-//                   M_k += g x^a y^b z^c in registers (pair_mtp.cpp:154-172); the table
-//                   row pitch is a compile-time constant so every LDS read is base
-//                   register + immediate; NG-way shuffle sum at the end
+//   3. basic moments the wavefront is NG neighbour groups x KL block lanes: lane (q, kl) owns NB blocks of
+//                   3 heads (g_s x^a) x 3 tails (y^b z^c) = 9 basics (tiled on the host) and the neighbours
+//                   n = q + NG m, and accumulates M_k += g x^a y^b z^c in registers (pair_mtp.cpp:154-172)
+//                   from 12 LDS reads per block and column; the table row pitch is a compile-time constant
+//                   so every LDS read is base register + immediate; NG-way permlane-swap sum at the end
 //   4. products     lanes = times rows, one dependency level at a time, moments and
 //                   adjoints in LDS with ds_add_f64 (pair_mtp.cpp:196-233)
 //   5. forces       per radial slot s = (mu, nu) the adjoints of its basics are the coefficients of a

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Compile every (KL, KB) instantiation of mtp_wave_kernel on its own and report registers,
+"""Compile every (KL, NB) instantiation of mtp_wave_kernel on its own and report registers,
 spills and compiler errors (hipcc 7.2 rejects some shapes with a machine-verifier error)."""
 import concurrent.futures
 import re
