@@ -89,6 +89,7 @@ struct mtp_context {
   // launch geometry
   struct LaunchPlan {
     int wpb = 1, grid = 1, wave_doubles = 0, tab_rows = 0, g_doubles = 0, m_doubles = 0, ov_doubles = 0;
+    bool rebuild = false;
     size_t lds_bytes = 0;
   } lp[2];   // [0] force calls (wavefront per atom), [1] candidate-vector kernel of grade calls
   DevBuf<double> d_cvec, d_ainv_pad, d_ainv_tiled, d_dbasic;
@@ -120,13 +121,31 @@ void mtp_context::plan()
     LaunchPlan &L = lp[0];
     L.tab_rows = 2 * p.slot_count + 3 * P;
     L.g_doubles = 0;
-    L.m_doubles = std::max(std::max(A, p.coef_total), 16);   // moments, later the derivative-polynomial coefficients
     const int d_doubles = A;
-    // coordinate-power rows and moments/adjoints share one overlay (never live together)
-    L.ov_doubles = std::max(3 * P * MTP_PITCH, d_doubles + L.m_doubles);
-    const size_t dbl = (size_t) 2 * p.slot_count * MTP_PITCH + L.ov_doubles + 5 * (size_t) nt;
     const size_t ints = (size_t) 2 * nt + cap;
-    const size_t wb = (dbl * 8 + ints * 4 + 15) / 16 * 16;
+    const int trows = 2 * p.slot_count * MTP_PITCH;   // g and dg rows
+    // coordinate-power rows and moments/adjoints share one overlay (never live together) ...
+    const int m_keep = std::max(std::max(A, p.coef_total), 16);   // moments, later the derivative-polynomial coefficients
+    const int ov_keep = std::max(3 * P * MTP_PITCH, d_doubles + m_keep);
+    const size_t wb_keep = (((size_t) trows + ov_keep + 5 * (size_t) nt) * 8 + ints * 4 + 15) / 16 * 16;
+    // ... and for potentials with many moments the g / dg rows can join the overlay, at the price of building them a
+    // second time ahead of the force phase (the coefficient blocks then sit behind the rows, D[0, B) in front)
+    const int m_reb = std::max(A, 16);
+    const int ov_reb = std::max(trows + std::max(3 * P * MTP_PITCH, p.coef_total), d_doubles + m_reb);
+    const size_t wb_reb = (((size_t) ov_reb + 5 * (size_t) nt) * 8 + ints * 4 + 15) / 16 * 16;
+    auto max_waves = [&](size_t wbytes) {
+      int best_v = 0;
+      for (int w = 1; w <= MTP_MAX_WPB; w++)
+        if (blob + w * wbytes <= LDS) best_v = std::max(best_v, std::min<int>(8, (int) (LDS / (blob + w * wbytes)) * w));
+      return best_v;
+    };
+    bool rebuild = trows >= p.alpha_index_basic_count && max_waves(wb_reb) > max_waves(wb_keep);
+    if (const char *e = std::getenv("MTP_REBUILD_TABLES"))   // tuning override (benchmarks only)
+      rebuild = std::atoi(e) != 0 && trows >= p.alpha_index_basic_count;
+    L.rebuild = rebuild;
+    L.m_doubles = rebuild ? m_reb : m_keep;
+    L.ov_doubles = rebuild ? ov_reb : ov_keep;
+    const size_t wb = rebuild ? wb_reb : wb_keep;
     // waves per CU for w waves per workgroup; registers allow 8 (2 per SIMD)
     auto waves_per_cu = [&](int w) {
       size_t blk = blob + w * wb;
@@ -698,6 +717,7 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
   p.tab_rows = L.tab_rows;
   p.m_doubles = L.m_doubles;
   p.ov_doubles = L.ov_doubles;
+  p.rebuild_tables = L.rebuild ? 1 : 0;
   p.wave_doubles = L.wave_doubles;
   p.cvec = grade_flag ? c->d_cvec.ptr : nullptr;
   p.cpad = c->cpad;

@@ -74,6 +74,7 @@ struct MtpDevParams {
   // launch geometry
   int NT;                  // neighbours per LDS tile: 32 (table row pitch MTP_PITCH doubles)
   int tab_rows;            // table rows = 2*nslot + 3*P (candidate-vector kernel: 4*P + R)
+  int rebuild_tables;      // moments / adjoints also overlay the g, dg rows; the rows are rebuilt ahead of the force phase
   int ov_doubles;          // force kernel: doubles of the overlay = max(3*P*MTP_PITCH, m_doubles + d_doubles)
   int cj_cap;              // capacity of the compacted id list
   int wave_doubles;        // LDS doubles per wavefront

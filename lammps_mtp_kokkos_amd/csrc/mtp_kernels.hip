@@ -69,7 +69,7 @@ static __device__ __forceinline__ KP kp_fresh()
 template <int PITCH> struct WaveLds {
   static constexpr int NT = 32;   // neighbours per tile; the row pitch (33 doubles: odd, so the 32 lanes of a half-wavefront
                                   // reading 32 different rows of one column hit 32 different 8-byte banks) is the template parameter
-  double *M, *D, *tab, *nbx, *nby, *nbz, *nbr, *nbi;
+  double *M, *D, *coef, *tab, *nbx, *nby, *nbz, *nbr, *nbi;
   int *nbj, *nbjt, *cj;
   unsigned m_addr;   // LDS byte address of M
   __device__ __forceinline__ unsigned addr(const double *ptr) const { return m_addr + 8u * (unsigned) (ptr - M); }
@@ -77,12 +77,23 @@ template <int PITCH> struct WaveLds {
   {
     // [g rows | dg rows | overlay | neighbour arrays]; the overlay holds the coordinate-power rows from
     // the tile build to the end of the basic-moment pass, and the moments / adjoints (later the
-    // derivative-polynomial coefficients) from there on -- the two are never live together
+    // derivative-polynomial coefficients) from there on -- the two are never live together.
+    // Potentials with many moments (rebuild_tables): the moments and adjoints also overlay the g / dg rows, which
+    // are then built a second time ahead of the force phase (the coefficient blocks sit behind the rows, the
+    // adjoints of the basics D[0, B) in front: the host checks that they cannot meet).
     tab = base;
-    M = tab + (size_t) 2 * kp->nslot * PITCH;
-    m_addr = base_addr + 8u * (unsigned) (2 * kp->nslot * PITCH);
-    D = M + kp->m_doubles;
-    nbx = M + kp->ov_doubles;
+    if (kp->rebuild_tables) {
+      D = tab;
+      M = D + kp->d_doubles;
+      coef = tab + (size_t) 2 * kp->nslot * PITCH;
+      nbx = tab + kp->ov_doubles;
+    } else {
+      M = tab + (size_t) 2 * kp->nslot * PITCH;
+      D = M + kp->m_doubles;
+      coef = M;
+      nbx = M + kp->ov_doubles;
+    }
+    m_addr = base_addr + 8u * (unsigned) (M - tab);
     nby = nbx + NT;
     nbz = nby + NT;
     nbr = nbz + NT;
@@ -666,7 +677,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
     // the (now free) moment region receives the coefficient blocks of the derivative polynomials:
     // basic k = (slot s; a, b, c) puts a D_k at the d/dx coefficient of x^(a-1) y^b z^c, b D_k and c D_k alike
     if (!kp->coef_dense) {   // monomials the potential does not list
-      for (int k = lane; k < kp->coef_total; k += 64) w.M[k] = 0.0;
+      for (int k = lane; k < kp->coef_total; k += 64) w.coef[k] = 0.0;
       wave_fence();
     }
     for (int k0 = 0; k0 < (GRADE && kp->dbasic ? max(kp->dpad, kp->B) : kp->B); k0 += 192) {
@@ -687,9 +698,9 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
         if (ok) {
           const unsigned t0 = (unsigned) tg[u].x, t1 = (unsigned) tg[u].y;
           const unsigned tx = t0 & 0xffffu, ty_ = t0 >> 16, tz_ = t1 & 0xffffu;
-          if (tx != 0xffffu) w.M[tx] = dd[u] * (double) ((t1 >> 16) & 15u);
-          if (ty_ != 0xffffu) w.M[ty_] = dd[u] * (double) ((t1 >> 20) & 15u);
-          if (tz_ != 0xffffu) w.M[tz_] = dd[u] * (double) ((t1 >> 24) & 15u);
+          if (tx != 0xffffu) w.coef[tx] = dd[u] * (double) ((t1 >> 16) & 15u);
+          if (ty_ != 0xffffu) w.coef[ty_] = dd[u] * (double) ((t1 >> 20) & 15u);
+          if (tz_ != 0xffffu) w.coef[tz_] = dd[u] * (double) ((t1 >> 24) & 15u);
         }
       }
     }
@@ -705,7 +716,8 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
       double crad = 0.0;
       for (int tile = 0; tile < ntiles; tile++) {
         const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-        if (ntiles > 1) build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, true, false, xi0, xi1, xi2, i, itype, lane);
+        if (ntiles > 1 || kp->rebuild_tables)
+          build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, ntiles > 1, false, xi0, xi1, xi2, i, itype, lane);
         // columns past ntp hold stale (finite or not) data: their lanes are masked at the end
         const double x = w.nbx[n], y = w.nby[n], z = w.nbz[n], inv = w.nbi[n];
         double UA = 0.0, VA = 0.0, UB = 0.0, VB = 0.0, S0 = 0.0;
@@ -714,7 +726,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
         {   // rank 0: P_s = D_k, no gradient
           unsigned cg = pcol + 8u * (unsigned) (ns * PITCH);
           for (int sidx = 0; sidx < kp->deg_first[1]; sidx++) {
-            const double dk = w.M[kp->deg_coef[0] + sidx];
+            const double dk = w.coef[kp->deg_coef[0] + sidx];
             S0 = fma(lds_ld(cg, 0), dk, S0);
             if (GRADE) {
               const int mu = bt.smu[sidx];
@@ -726,7 +738,7 @@ __global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_a
         }
         double mono[DEG * (DEG + 1) / 2];
         mono[0] = 1.0;
-        force_degree<1, DEG, PITCH, GRADE>(kp, pcol, w.m_addr, part, x, y, z, mono, UA, VA, UB, VB, bt.smu, inv, inv, Wm);
+        force_degree<1, DEG, PITCH, GRADE>(kp, pcol, w.addr(w.coef), part, x, y, z, mono, UA, VA, UB, VB, bt.smu, inv, inv, Wm);
         if (fused) {
           // c[jt][mu][ri] += sum_n [type_n = jt] Q_ri(r_n) W_mu(n)  (pair_mtp_extrapolation.cpp:193-198, 323-329):
           // half h of the wavefront reduces the 32 (mu, ri) entries of jt = h over its 32 neighbour lanes
