@@ -133,10 +133,14 @@ void mtp_context::plan()
     const int m_reb = std::max(A, 16);
     const int ov_reb = std::max(trows + std::max(3 * P * MTP_PITCH, p.coef_total), d_doubles + m_reb);
     const size_t wb_reb = (((size_t) ov_reb + 5 * (size_t) nt) * 8 + ints * 4 + 15) / 16 * 16;
+    // registers allow 8 wavefronts per CU (2 per SIMD at <= 256 VGPRs); MTP_MAX_WAVES overrides for experiments with
+    // builds that cap the kernel at 168 VGPRs (3 per SIMD)
+    int wave_cap = 8;
+    if (const char *e = std::getenv("MTP_MAX_WAVES")) wave_cap = std::max(1, std::min(16, std::atoi(e)));
     auto max_waves = [&](size_t wbytes) {
       int best_v = 0;
       for (int w = 1; w <= MTP_MAX_WPB; w++)
-        if (blob + w * wbytes <= LDS) best_v = std::max(best_v, std::min<int>(8, (int) (LDS / (blob + w * wbytes)) * w));
+        if (blob + w * wbytes <= LDS) best_v = std::max(best_v, std::min<int>(wave_cap, (int) (LDS / (blob + w * wbytes)) * w));
       return best_v;
     };
     bool rebuild = trows >= p.alpha_index_basic_count && max_waves(wb_reb) > max_waves(wb_keep);
@@ -150,7 +154,7 @@ void mtp_context::plan()
     auto waves_per_cu = [&](int w) {
       size_t blk = blob + w * wb;
       if (blk > LDS) return 0;
-      return std::min<int>(8, (int) (LDS / blk) * w);
+      return std::min<int>(wave_cap, (int) (LDS / blk) * w);
     };
     // few atoms (or the "small" variant): the finest spread that still reaches the best occupancy;
     // many atoms: as many wavefronts per workgroup as possible (fewer copies of the table blob)
@@ -345,7 +349,8 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
       if (8 * wb + others + rows8.size() * sizeof(MtpRow8) <= 160 * 1024) bb.rows_in_lds = 1;
     }
     if (const char *e = std::getenv("MTP_ROWS_LDS")) {   // tuning override (benchmarks only)
-      if (std::atoi(e) != 0 && rows8.size() * sizeof(MtpRow8) <= 24 * 1024) bb.rows_in_lds = 1;
+      if (std::atoi(e) == 0) bb.rows_in_lds = 0;
+      else if (rows8.size() * sizeof(MtpRow8) <= 24 * 1024) bb.rows_in_lds = 1;
     }
     std::vector<unsigned char> blob;
     auto put = [&](const void *src, size_t bytes) {

@@ -390,8 +390,11 @@ __device__ __forceinline__ void force_degree(KP kp, unsigned pcol, unsigned pcoe
   }
 }
 
+#ifndef MTP_WAVES_PER_SIMD
+#define MTP_WAVES_PER_SIMD 2
+#endif
 template <int KL, int NB, int PITCH, bool GRADE, int DEG>
-__global__ void __launch_bounds__(512, 2) mtp_wave_kernel(const MtpDevParams p_arg)
+__global__ void __launch_bounds__(512, MTP_WAVES_PER_SIMD) mtp_wave_kernel(const MtpDevParams p_arg)
 {
   constexpr int NT = 32;                 // neighbours per tile
   constexpr int NG = 64 / KL;            // neighbour groups in the wavefront
