@@ -91,3 +91,39 @@ def test_device_resident_nve_matches_host_driven_loop():
     assert md.builds >= 4                                   # re-neighboured on the device along the way
     assert np.abs(md.x.cpu().numpy() - pc).max() < 1e-10 and np.abs(md.v.cpu().numpy() - vc).max() < 1e-9
     assert np.abs(np.array(eg) - ec).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_device_resident_nve_level16_follows_oracle():
+    """The device-resident loop at level 16 (the headline kernel shape): 432 atoms, 30 steps of 0.25 fs from 30 K,
+    list rebuilt on the GPU every 5 steps, against the oracle-driven integrator.  (The synthetic random-coefficient
+    potential is stiff and not bounded like a fitted one: a BCC lattice is not its minimum, so the run is kept short
+    and cold; trajectory agreement, not long-time energy conservation, is the check.)"""
+    import torch
+    from oracle.pyoracle import Oracle
+    from lammps_mtp_kokkos_amd.md import DeviceNVE
+    path = os.path.join(ROOT, "potentials", "W_L16.mtp")
+    pos0, box = mtpgen.bcc_lattice(6, 6, 6)
+    rng = np.random.default_rng(17)
+    vel0 = rng.normal(size=pos0.shape) * np.sqrt(KB * 30.0 / (MASS * MVV2E))
+    vel0 -= vel0.mean(0)
+    pot = capi.Potential(path)
+    ctx = capi.Context(pot, 0)
+    orc = Oracle(path)
+
+    def cpu_force(p):
+        s = periodic_system(p, box, None, 7.0)
+        r = orc.compute(s.x, s.types, s.ilist, s.first, s.neigh, eflag=1, vflag=0)
+        return s.fold_forces(r["f"]), r["energy"]
+
+    md = DeviceNVE(ctx, pos0.copy(), box, rc=pot.info.max_cutoff, mass=MASS, list_cutoff=7.0, every=5)
+    md.v.copy_(torch.from_numpy(vel0))
+    eg = []
+    for _ in range(30):
+        md.step(2.5e-4)
+        eg.append(md.total_energy())
+    pc, vc, ec = _run(cpu_force, pos0.copy(), box, vel0.copy(), 30, 2.5e-4)
+    assert md.builds >= 6
+    assert np.abs(md.x.cpu().numpy() - pc).max() < 1e-9 and np.abs(md.v.cpu().numpy() - vc).max() < 1e-7
+    assert np.abs(np.array(eg) - ec).max() < 1e-7
+    assert abs(float(md.v.mean())) < 1e-9            # momentum conserved (forces sum to zero)
