@@ -471,14 +471,21 @@ int mtp_potential::finalize(std::string &err)
   moment_perm.resize((size_t) A);
   for (int m = 0; m < A; m++) moment_perm[m] = m;
   if (A - B >= 2 && !rows_by_level.empty()) {
-    const int ngroups = (int) rows_by_level.size() / 32;
+    // access granularity of the model: MTP_BANK_GROUP rows (lanes) compete for the 32 eight-byte banks, FREE distinct
+    // addresses per bank are free
+    int GRP = 32, FREE = 1;
+    if (const char *e = std::getenv("MTP_BANK_GROUP")) {
+      GRP = std::atoi(e) == 64 ? 64 : (std::atoi(e) == 16 ? 16 : 32);
+      FREE = GRP == 64 ? 2 : 1;
+    }
+    const int ngroups = (int) rows_by_level.size() / GRP;
     const int weight[3] = {3, 3, 2};   // a0, a1: two reads + one atomic each; a3: one read + one atomic
     std::vector<std::vector<int>> occ((size_t) A);            // moment -> (group * 3 + stream) it appears in (distinct)
     std::vector<uint8_t> hist((size_t) ngroups * 3 * 32, 0);  // distinct moments per bank of each access
     for (int g = 0; g < ngroups; g++)
       for (int st = 0; st < 3; st++) {
         std::vector<int> seen;
-        for (int r = 32 * g; r < 32 * g + 32; r++) {
+        for (int r = GRP * g; r < GRP * g + GRP; r++) {
           const MtpRow &row = rows_by_level[(size_t) r];
           const int m = st == 0 ? row.a0 : (st == 1 ? row.a1 : row.a3);
           if (std::find(seen.begin(), seen.end(), m) == seen.end()) {
@@ -488,7 +495,7 @@ int mtp_potential::finalize(std::string &err)
           }
         }
       }
-    auto pen = [](int n) { return n > 1 ? n - 1 : 0; };
+    auto pen = [FREE](int n) { return n > FREE ? n - FREE : 0; };
     std::vector<int> bank((size_t) A);
     for (int m = 0; m < A; m++) bank[m] = m & 31;
     auto move_delta = [&](int m, int from, int to, int other) {   // cost change of moving m between banks
@@ -500,6 +507,13 @@ int mtp_potential::finalize(std::string &err)
       }
       return d;
     };
+    auto total_cost = [&]() {
+      long long c = 0;
+      for (size_t gs = 0; gs < hist.size() / 32; gs++)
+        for (int b = 0; b < 32; b++) c += (long long) weight[gs % 3] * pen(hist[gs * 32 + b]);
+      return c;
+    };
+    const long long cost_before = total_cost();
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     auto next = [&]() {
       rng = rng * 6364136223846793005ull + 1442695040888963407ull;
@@ -525,6 +539,9 @@ int mtp_potential::finalize(std::string &err)
       std::swap(bank[m1], bank[m2]);
       std::swap(moment_perm[m1], moment_perm[m2]);
     }
+    if (std::getenv("MTP_DEBUG_BANKS"))
+      std::fprintf(stderr, "mtp: LDS bank model cost of the product passes %lld -> %lld (%d accesses of %d rows)\n",
+                   cost_before, total_cost(), ngroups * 3, GRP);
     for (MtpRow &row : rows_by_level) {
       row.a0 = moment_perm[row.a0];
       row.a1 = moment_perm[row.a1];
