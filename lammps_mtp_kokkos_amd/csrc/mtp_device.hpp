@@ -12,7 +12,7 @@
 #define MTP_PSTRIDE 12      // slot ids per mu in the LDS blob (nu = 0..11, -1 padded)
 
 // A times row packed in 8 bytes: lo = a0 | a1 << 16, hi = a3 | (mult & 0xffff) << 16
-struct MtpRow8 {
+struct alignas(8) MtpRow8 {   // 8-byte aligned: one ds_read_b64 / global_load_dwordx2 per row, not two dword reads
   uint32_t lo, hi;
 };
 

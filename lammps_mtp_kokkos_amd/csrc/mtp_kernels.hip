@@ -642,8 +642,10 @@ __global__ void __launch_bounds__(512, MTP_WAVES_PER_SIMD) mtp_wave_kernel(const
     wave_fence();
 
     // ---- 4a. products, level by level (pair_mtp.cpp:196-201) -----------------------------
+#ifndef MTP_EXP_NOPRODUCTS   // timing / counter experiment only (wrong results)
     if (rows_lds) products_forward<MTP_PU>(bt.rows, bt.level, kp->nlevels, w.M, lane);
     else products_forward<MTP_PU>(kp->rows, bt.level, kp->nlevels, w.M, lane);
+#endif
     STAMP(4);   // products forward
     KP_FRESH();
     // ---- candidate vector, species and linear blocks (pair_mtp_extrapolation.cpp:235-252) ----
@@ -671,8 +673,10 @@ __global__ void __launch_bounds__(512, MTP_WAVES_PER_SIMD) mtp_wave_kernel(const
     wave_fence();
     STAMP(5);   // energy + seeds
     KP_FRESH();
+#ifndef MTP_EXP_NOPRODUCTS
     if (rows_lds) products_backward<MTP_PU>(bt.rows, bt.level, kp->nlevels, w.M, w.D, lane);
     else products_backward<MTP_PU>(kp->rows, bt.level, kp->nlevels, w.M, w.D, lane);
+#endif
 
     STAMP(6);   // products backward
     KP_FRESH();
