@@ -386,7 +386,7 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     bb.g_seed_val = c->d_seed_val.ptr;
     bb.g_map = c->d_map.ptr;
     bb.g_lin = c->d_lin.ptr;
-    bb.off_pack = put(pot->basic_pack.data(), pot->basic_pack.size() * sizeof(int32_t));
+    bb.off_pack = put(pot->basic_pack_lds.data(), pot->basic_pack_lds.size() * sizeof(int32_t));
     bb.off_coef = put(pot->basic_tgt.data(), pot->basic_tgt.size() * sizeof(int32_t));
     bb.off_smu = put(pot->slot_mu.data(), pot->slot_mu.size() * sizeof(int32_t));
     bb.off_fwd = put(pot->fwd_blocks.data(), pot->fwd_blocks.size() * sizeof(int32_t));

@@ -463,85 +463,153 @@ int mtp_potential::finalize(std::string &err)
         seed_val.push_back(linear_coeffs[last[m]]);
       }
   }
-  // LDS placement of the product moments: the product passes touch M[a0], M[a1], M[a3] / D[...] of 32
-  // consecutive rows per half-wavefront access, and moments that share an 8-byte bank (index mod 32) but not an
-  // address serialise.  The row order is fixed by now; renumber the moments [B, A) (basics keep their numbers: the
-  // basic-moment pass and the coefficient blocks address them by k) by pairwise swaps that lower the number of
-  // same-bank distinct moments per access.  Deterministic (fixed-seed LCG).  moment_perm[old] = new.
+  // LDS numbering of the moments.  The product passes read M[a0], M[a1], D[a3] (ds_read_b64: the two 32-lane halves
+  // of a wave instruction are banked separately over 32 eight-byte banks) and add into M[a3], D[a0], D[a1]
+  // (ds_add_f64, banked like ds_write_b64: four 16-lane groups over 16 eight-byte banks); distinct moments of one
+  // group on one bank serialise (MI355X_MICROARCH.md, LDS table).  The row order is fixed by now: renumber the
+  // moments -- basics among [0, B), products among [B, A), so the zero-fill and the k < B loops of the kernel keep
+  // working -- by pairwise swaps that lower the modelled extra cycles.  Deterministic (fixed-seed LCG).
+  // moment_perm[file index] = LDS index; every device table below is written in LDS numbering.
   moment_perm.resize((size_t) A);
   for (int m = 0; m < A; m++) moment_perm[m] = m;
-  if (A - B >= 2 && !rows_by_level.empty()) {
-    // access granularity of the model: MTP_BANK_GROUP rows (lanes) compete for the 32 eight-byte banks, FREE distinct
-    // addresses per bank are free
-    int GRP = 32, FREE = 1;
-    if (const char *e = std::getenv("MTP_BANK_GROUP")) {
-      GRP = std::atoi(e) == 64 ? 64 : (std::atoi(e) == 16 ? 16 : 32);
-      FREE = GRP == 64 ? 2 : 1;
-    }
-    const int ngroups = (int) rows_by_level.size() / GRP;
-    const int weight[3] = {3, 3, 2};   // a0, a1: two reads + one atomic each; a3: one read + one atomic
-    std::vector<std::vector<int>> occ((size_t) A);            // moment -> (group * 3 + stream) it appears in (distinct)
-    std::vector<uint8_t> hist((size_t) ngroups * 3 * 32, 0);  // distinct moments per bank of each access
-    for (int g = 0; g < ngroups; g++)
-      for (int st = 0; st < 3; st++) {
-        std::vector<int> seen;
-        for (int r = GRP * g; r < GRP * g + GRP; r++) {
-          const MtpRow &row = rows_by_level[(size_t) r];
-          const int m = st == 0 ? row.a0 : (st == 1 ? row.a1 : row.a3);
-          if (std::find(seen.begin(), seen.end(), m) == seen.end()) {
-            seen.push_back(m);
-            occ[(size_t) m].push_back(g * 3 + st);
-            hist[((size_t) g * 3 + st) * 32 + (m & 31)]++;
-          }
-        }
-      }
-    auto pen = [FREE](int n) { return n > FREE ? n - FREE : 0; };
-    std::vector<int> bank((size_t) A);
-    for (int m = 0; m < A; m++) bank[m] = m & 31;
-    auto move_delta = [&](int m, int from, int to, int other) {   // cost change of moving m between banks
-      int d = 0;
-      for (int gs : occ[(size_t) m]) {
-        if (std::binary_search(occ[(size_t) other].begin(), occ[(size_t) other].end(), gs)) continue;   // both swap: no change
-        const uint8_t *h = &hist[(size_t) gs * 32];
-        d += weight[gs % 3] * (pen(h[from] - 1) + pen(h[to] + 1) - pen(h[from]) - pen(h[to]));
-      }
-      return d;
+  if (A >= 2 && !rows_by_level.empty() && !std::getenv("MTP_NO_RENUMBER")) {
+    struct Access {
+      int nbk, w;
     };
-    auto total_cost = [&]() {
-      long long c = 0;
-      for (size_t gs = 0; gs < hist.size() / 32; gs++)
-        for (int b = 0; b < 32; b++) c += (long long) weight[gs % 3] * pen(hist[gs * 32 + b]);
-      return c;
-    };
-    const long long cost_before = total_cost();
+    const int w_read[3] = {2, 2, 1}, w_add[3] = {1, 1, 1};   // a0, a1 are read in both passes, D[a3] in the reverse one
+    auto pen = [](int n) { return n > 1 ? n - 1 : 0; };
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     auto next = [&]() {
       rng = rng * 6364136223846793005ull + 1442695040888963407ull;
       return (uint32_t) (rng >> 33);
     };
-    const int movable = A - B;
-    const long long trials = std::min<long long>(400ll * movable, 2000000ll);
-    for (long long t = 0; t < trials; t++) {
-      const int m1 = B + (int) (next() % (uint32_t) movable), m2 = B + (int) (next() % (uint32_t) movable);
-      const int b1 = bank[m1], b2 = bank[m2];
-      if (b1 == b2) continue;
-      if (move_delta(m1, b1, b2, m2) + move_delta(m2, b2, b1, m1) >= 0) continue;
-      for (int gs : occ[(size_t) m1])
-        if (!std::binary_search(occ[(size_t) m2].begin(), occ[(size_t) m2].end(), gs)) {
-          hist[(size_t) gs * 32 + b1]--;
-          hist[(size_t) gs * 32 + b2]++;
+    // extra cycles of one group of rows [r0, r0 + grp) under the current numbering
+    // reads of one address broadcast (count distinct moments); adds to one address serialise (count rows)
+    auto group_cost = [&](int r0, int grp, int nbk, const int w3[3], bool distinct) {
+      int c = 0;
+      for (int st = 0; st < 3; st++) {
+        int seen[32], ns = 0;
+        uint8_t h[32] = {0};
+        for (int r = r0; r < r0 + grp; r++) {
+          const MtpRow &row = rows_by_level[(size_t) r];
+          const int m = moment_perm[st == 0 ? row.a0 : (st == 1 ? row.a1 : row.a3)];
+          bool dup = false;
+          if (distinct)
+            for (int q = 0; q < ns; q++) dup |= seen[q] == m;
+          if (!dup) {
+            seen[ns++] = m;
+            h[m % nbk]++;
+          }
         }
-      for (int gs : occ[(size_t) m2])
-        if (!std::binary_search(occ[(size_t) m1].begin(), occ[(size_t) m1].end(), gs)) {
-          hist[(size_t) gs * 32 + b2]--;
-          hist[(size_t) gs * 32 + b1]++;
+        for (int b = 0; b < nbk; b++) c += w3[st] * pen(h[b]);
+      }
+      return c;
+    };
+    auto total_cost = [&]() {
+      long long c = 0;
+      for (size_t r0 = 0; r0 < rows_by_level.size(); r0 += 32) c += group_cost((int) r0, 32, 32, w_read, true);
+      for (size_t r0 = 0; r0 < rows_by_level.size(); r0 += 16) c += group_cost((int) r0, 16, 16, w_add, false);
+      return c;
+    };
+    const long long cost_before = total_cost();
+    for (int round = 0; round < 2; round++) {   // (load-time budget: ~0.2 s at level 16, ~2 s at level 20)
+      // ---- (a) renumber moments, rows fixed ----------------------------------------------------------
+      std::vector<Access> acc;
+      // moment (file index) -> (access, weight of the moment in it: 1 for reads, its row count for adds), ascending
+      std::vector<std::vector<std::pair<int, int>>> occ((size_t) A);
+      std::vector<uint8_t> hist;                       // [access][32]: load per bank
+      auto add_accesses = [&](int grp, int nbk, const int w3[3], bool distinct) {
+        const int ngroups = (int) rows_by_level.size() / grp;
+        for (int g = 0; g < ngroups; g++)
+          for (int st = 0; st < 3; st++) {
+            const int id = (int) acc.size();
+            acc.push_back({nbk, w3[st]});
+            hist.resize(hist.size() + 32, 0);
+            for (int r = grp * g; r < grp * g + grp; r++) {
+              const MtpRow &row = rows_by_level[(size_t) r];
+              const int m = st == 0 ? row.a0 : (st == 1 ? row.a1 : row.a3);
+              auto &o = occ[(size_t) m];
+              if (!o.empty() && o.back().first == id) {
+                if (distinct) continue;
+                o.back().second++;
+              } else {
+                o.push_back({id, 1});
+              }
+              hist[(size_t) id * 32 + (moment_perm[m] % nbk)]++;
+            }
+          }
+      };
+      add_accesses(32, 32, w_read, true);
+      add_accesses(16, 16, w_add, false);
+      auto mult_in = [&](int m, int id) {   // rows (adds) / 1 (reads) of moment m in access id, 0 if absent
+        const auto &o = occ[(size_t) m];
+        auto it = std::lower_bound(o.begin(), o.end(), std::make_pair(id, 0));
+        return it != o.end() && it->first == id ? it->second : 0;
+      };
+      // cost change of swapping the numbers of m (at `from`) and other (at `to`), counted over m's accesses; accesses
+      // holding both are counted once, from the smaller moment
+      auto move_delta = [&](int m, int from, int to, int other) {
+        int d = 0;
+        for (const auto &e : occ[(size_t) m]) {
+          const int id = e.first, k = e.second, k2 = mult_in(other, id);
+          if (k2 > 0 && m > other) continue;
+          const int f = from % acc[(size_t) id].nbk, t = to % acc[(size_t) id].nbk;
+          if (f == t) continue;
+          const uint8_t *h = &hist[(size_t) id * 32];
+          d += acc[(size_t) id].w * (pen(h[f] - k + k2) + pen(h[t] + k - k2) - pen(h[f]) - pen(h[t]));
         }
-      std::swap(bank[m1], bank[m2]);
-      std::swap(moment_perm[m1], moment_perm[m2]);
+        return d;
+      };
+      auto apply_move = [&](int m, int from, int to, int other) {
+        for (const auto &e : occ[(size_t) m]) {
+          const int id = e.first, k = e.second, k2 = mult_in(other, id);
+          if (k2 > 0 && m > other) continue;
+          const int f = from % acc[(size_t) id].nbk, t = to % acc[(size_t) id].nbk;
+          if (f == t) continue;
+          hist[(size_t) id * 32 + f] = (uint8_t) (hist[(size_t) id * 32 + f] - k + k2);
+          hist[(size_t) id * 32 + t] = (uint8_t) (hist[(size_t) id * 32 + t] + k - k2);
+        }
+      };
+      const long long trials = std::min<long long>(200ll * A, 300000ll);
+      for (long long t = 0; t < trials; t++) {
+        int m1 = (int) (next() % (uint32_t) A), m2;
+        if (m1 < B) {
+          if (B < 2) continue;
+          m2 = (int) (next() % (uint32_t) B);
+        } else {
+          if (A - B < 2) continue;
+          m2 = B + (int) (next() % (uint32_t) (A - B));
+        }
+        if (m1 == m2) continue;
+        const int p1 = moment_perm[m1], p2 = moment_perm[m2];
+        if (move_delta(m1, p1, p2, m2) + move_delta(m2, p2, p1, m1) >= 0) continue;
+        apply_move(m1, p1, p2, m2);
+        apply_move(m2, p2, p1, m1);
+        std::swap(moment_perm[m1], moment_perm[m2]);
+      }
+      // ---- (b) swap rows inside a level (they commute), numbering fixed -----------------------------------
+      const int nlev2 = (int) level_offset.size() - 1;
+      const long long rtrials = std::min<long long>(100ll * (long long) rows_by_level.size(), 250000ll);
+      for (long long t = 0; t < rtrials; t++) {
+        const int l = (int) (next() % (uint32_t) nlev2);
+        const int b = level_offset[l], n = level_offset[l + 1] - b;
+        if (n < 2) continue;
+        const int r1 = b + (int) (next() % (uint32_t) n), r2 = b + (int) (next() % (uint32_t) n);
+        if (r1 / 16 == r2 / 16) continue;   // same add group (hence same read group): nothing changes
+        auto local = [&]() {
+          int c = group_cost(r1 / 16 * 16, 16, 16, w_add, false) + group_cost(r2 / 16 * 16, 16, 16, w_add, false);
+          c += group_cost(r1 / 32 * 32, 32, 32, w_read, true);
+          if (r1 / 32 != r2 / 32) c += group_cost(r2 / 32 * 32, 32, 32, w_read, true);
+          return c;
+        };
+        const int c0 = local();
+        std::swap(rows_by_level[(size_t) r1], rows_by_level[(size_t) r2]);
+        if (local() >= c0) std::swap(rows_by_level[(size_t) r1], rows_by_level[(size_t) r2]);
+      }
     }
     if (std::getenv("MTP_DEBUG_BANKS"))
-      std::fprintf(stderr, "mtp: LDS bank model cost of the product passes %lld -> %lld (%d accesses of %d rows)\n",
-                   cost_before, total_cost(), ngroups * 3, GRP);
+      std::fprintf(stderr, "mtp: LDS bank model of the product passes: %lld -> %lld extra cycles per atom\n", cost_before,
+                   total_cost());
     for (MtpRow &row : rows_by_level) {
       row.a0 = moment_perm[row.a0];
       row.a1 = moment_perm[row.a1];
@@ -612,8 +680,9 @@ int mtp_potential::finalize(std::string &err)
       if (c > 0) tz = (uint32_t) (base + 2 * C + (j - 1) * j / 2 + c - 1);
       for (uint32_t t : {tx, ty, tz})
         if (t != 0xffffu) hits[t]++;
-      basic_tgt[2 * (size_t) i] = (int32_t) (tx | (ty << 16));
-      basic_tgt[2 * (size_t) i + 1] = (int32_t) (tz | (fa << 16) | ((uint32_t) b << 20) | ((uint32_t) c << 24));
+      // stored at the basic's LDS number: the kernel walks D[k], tgt[k] with k in LDS numbering
+      basic_tgt[2 * (size_t) moment_perm[i]] = (int32_t) (tx | (ty << 16));
+      basic_tgt[2 * (size_t) moment_perm[i] + 1] = (int32_t) (tz | (fa << 16) | ((uint32_t) b << 20) | ((uint32_t) c << 24));
     }
     // head x tail blocks of the basic-moment pass
     {
@@ -652,7 +721,7 @@ int mtp_potential::finalize(std::string &err)
                 const int k = basic_of[(((size_t) heads[h0 + h].first * 16 + heads[h0 + h].second) * 16 +
                                         tails[t0 + t].first) * 16 + tails[t0 + t].second];
                 if (k >= 0) {
-                  kk[3 * h + t] = (int16_t) k;
+                  kk[3 * h + t] = (int16_t) moment_perm[k];   // LDS numbering
                   covered[k]++;
                   any = true;
                 }
@@ -669,6 +738,9 @@ int mtp_potential::finalize(std::string &err)
           return MTP_ERR_TABLE;
         }
     }
+    // packed basic descriptors in LDS numbering (mtp_cvec_kernel pairs them with dbasic[k] = D[k])
+    basic_pack_lds.assign((size_t) B, 0);
+    for (int i = 0; i < B; i++) basic_pack_lds[(size_t) moment_perm[i]] = basic_pack[i];
     coef_dense = 1;
     for (int t = 0; t < coef_total; t++) {
       if (hits[t] > 1) {

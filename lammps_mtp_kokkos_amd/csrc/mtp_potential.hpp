@@ -36,7 +36,7 @@ struct mtp_potential {
   // LDS numbering of the moments (moment_perm[file index] = LDS index; identity on the basics) chosen to spread
   // the product passes over the LDS banks; rows_by_level and seed_idx are already in LDS numbering,
   // mapping_lds = alpha_moment_mapping in LDS numbering
-  std::vector<int32_t> moment_perm, mapping_lds;
+  std::vector<int32_t> moment_perm, mapping_lds, basic_pack_lds;
   // distinct (mu, nu) pairs used by the basics -> slot; slot_of[mu*P+nu] or -1
   std::vector<int32_t> slot_of;
   int slot_count = 0;
