@@ -6,12 +6,15 @@ the level-16 potential (BASELINE.json configs[1]) on N MI355X of one node.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one force call on positions already resident in HBM: zero the force array,
-(N > 1: forward halo of ghost positions over RCCL), the fused MTP kernel with global
-energy and virial tallies, (N > 1: reverse halo of ghost forces).  N > 1 shards the SAME
-65,536 atoms by spatial domain decomposition (strong scaling, as BASELINE.json's metric
-asks).  Rank 0 prints one JSON line; `roofline` prices the dominant kernel against its
-algorithmic HBM bytes and `cpu_baseline` times the CPU oracle on this
-box's host cores in the same run.
+(N > 1: forward halo of ghost positions), the fused MTP kernel with global energy and virial
+tallies, (N > 1: reverse halo of ghost forces).  N > 1 shards the SAME 65,536 atoms by
+spatial domain decomposition (strong scaling, as BASELINE.json's metric asks); the halo is
+the library's own (mtp_halo_*: device pack / unpack + one grouped RCCL send/recv per
+direction on its own stream) and the owned atoms run as interior | boundary | interior row
+ranges so both exchanges overlap force work -- no torch collective in the timed loop.
+Rank 0 prints one JSON line; `roofline` prices the dominant kernel against its algorithmic
+HBM bytes and `cpu_baseline` times the CPU oracle on this box's host
+cores in the same run.
 """
 import argparse
 import json
@@ -58,7 +61,7 @@ def main():
     import torch
     import torch.distributed as dist
     from lammps_mtp_kokkos_amd import capi, mtpgen
-    from lammps_mtp_kokkos_amd.domain import HaloExchange, decompose
+    from lammps_mtp_kokkos_amd.domain import HaloExchange, decompose, overlap_order
 
     # BASELINE.json configs other than the headline one (the default is untouched by these)
     cells3 = (args.cells,) * 3
@@ -107,49 +110,64 @@ def main():
     sizes = pot.sizes
     ctx = capi.Context(pot, devidx)
     ctx.set_variant(dict(auto=0, large=1, small=2)[args.variant])
-    il = torch.from_numpy(plan.ilist).to(dev)
-    fi = torch.from_numpy(plan.first).to(dev)
-    ne = torch.from_numpy(plan.neigh).to(dev)
-    max_nn = int(np.diff(plan.first).max()) if plan.nlocal else 0
+    # N > 1: the rows are ordered interior | boundary | interior (atoms whose list holds no ghost are "interior")
+    halo_kind = os.environ.get("MTP_BENCH_HALO", "native" if backend == "nccl" else "torch")
+    use_rows = world > 1 and os.environ.get("MTP_BENCH_OVERLAP", "1") != "0"
+    if use_rows:
+        ilist_np, first_np, neigh_np, (n_a, n_b, n_c) = overlap_order(plan)
+    else:
+        ilist_np, first_np, neigh_np = plan.ilist, plan.first, plan.neigh
+        n_a, n_b, n_c = 0, plan.nlocal, 0
+    il = torch.from_numpy(ilist_np).to(dev)
+    fi = torch.from_numpy(first_np).to(dev)
+    ne = torch.from_numpy(neigh_np).to(dev)
+    max_nn = int(np.diff(first_np).max()) if plan.nlocal else 0
     ctx.set_neighbors_device(il, fi, ne, plan.nall, max_nn)
     x = torch.from_numpy(plan.x0).to(dev)
     ty = torch.from_numpy(plan.types).to(dev)
     f = torch.zeros((plan.nall, 3), dtype=torch.float64, device=dev)
     ev = torch.zeros(8, dtype=torch.float64, device=dev)
-    halo = HaloExchange(plan, dev)
-    stream = capi.use_private_torch_stream(dev).cuda_stream   # torch ops, collectives and the HIP kernels on ONE stream
+    stream = capi.use_private_torch_stream(dev).cuda_stream   # torch ops and the library's kernels on ONE stream
     EFLAG, VFLAG = 1, 1
     grades_t = torch.zeros(plan.nall, dtype=torch.float64, device=dev) if grade else None
     maxg_t = torch.zeros(1, dtype=torch.float64, device=dev) if grade else None
 
-    # N > 1: atoms whose list holds no ghost are computed while the forward halo is in flight
-    overlap = world > 1 and not grade and os.environ.get("MTP_BENCH_OVERLAP", "1") != "0"
-    if overlap:
-        from lammps_mtp_kokkos_amd.domain import split_interior, sub_list
-        rows_int, rows_bnd = split_interior(plan)
-        parts = []
-        for rows in (rows_int, rows_bnd):
-            c2 = capi.Context(pot, devidx)
-            c2.set_variant(dict(auto=0, large=1, small=2)[args.variant])
-            il2, fi2, ne2 = (torch.from_numpy(a).to(dev) for a in sub_list(plan, rows))
-            c2.set_neighbors_device(il2, fi2, ne2, plan.nall, max_nn)
-            parts.append(c2)
-        ctx_int, ctx_bnd = parts
+    # the halo: the library's RCCL exchange (production), or the torch twin (gloo rehearsals on one GPU)
+    halo, halo_info = None, None
+    if world > 1:
+        if halo_kind == "native":
+            store = dist.distributed_c10d._get_default_store()     # rendezvous plumbing only: 128 bytes, once
+            if rank == 0:
+                store.set("mtp_halo_unique_id", capi.halo_unique_id())
+            uid = bytes(store.get("mtp_halo_unique_id"))
+            halo = capi.Halo(plan, devidx, uid)
+            halo_info = halo.comm_count()
+            assert halo_info["nranks"] == world and halo_info["rank"] == rank
+        else:
+            halo = HaloExchange(plan, dev)
+
+    kw = dict(eflag=EFLAG, vflag=VFLAG, grade=grade, grades_t=grades_t, maxg_t=maxg_t, stream=stream)
 
     def step():
         f.zero_()
-        if overlap:
+        if world == 1:
+            ctx.compute_device(x, ty, f, ev_t=ev, **kw)
+        elif halo_kind == "native":
+            halo.forward_begin(x, stream)
+            if n_a:
+                ctx.compute_device_rows(0, n_a, False, x, ty, f, **kw)
+            halo.forward_end(stream)
+            ctx.compute_device_rows(n_a, n_b, n_c == 0, x, ty, f, ev_t=ev, **kw)
+            halo.reverse_begin(f, stream)
+            if n_c:
+                ctx.compute_device_rows(n_a + n_b, n_c, True, x, ty, f, ev_t=ev, **kw)
+            halo.reverse_end(f, stream)
+        else:
             h = halo.forward_begin(x)
-            ctx_int.compute_device(x, ty, f, eflag=EFLAG, vflag=VFLAG, ev_t=ev, stream=stream)
+            if n_a:
+                ctx.compute_device_rows(0, n_a, False, x, ty, f, **kw)
             halo.forward_end(h)
-            ctx_bnd.compute_device(x, ty, f, eflag=EFLAG, vflag=VFLAG, ev_t=ev, stream=stream)
-            halo.reverse(f)
-            return
-        if world > 1:
-            halo.forward(x)
-        ctx.compute_device(x, ty, f, eflag=EFLAG, vflag=VFLAG, ev_t=ev, stream=stream, grade=grade,
-                           grades_t=grades_t, maxg_t=maxg_t)
-        if world > 1:
+            ctx.compute_device_rows(n_a, n_b + n_c, True, x, ty, f, ev_t=ev, **kw)
             halo.reverse(f)
 
     def fence():
@@ -189,7 +207,7 @@ def main():
     # in-cutoff pair count of this rank (for the reference flop model), on the device
     with torch.no_grad():
         cnt = torch.diff(fi.long())
-        row = torch.repeat_interleave(torch.arange(plan.nlocal, device=dev), cnt)
+        row = torch.repeat_interleave(il.long(), cnt)
         d = x[ne.long()] - x[row]
         jc_total = int(((d * d).sum(1) <= pot.info.max_cutoff ** 2).sum().item())
     bytes_alg = algorithmic_bytes(int(plan.first[-1]), plan.nall, plan.nlocal)
@@ -270,6 +288,7 @@ def main():
     if rank == 0:
         value = natoms * args.steps / dt
         info = ctx.launch_info()
+        info.update(ctx.plan_info())
         line = {
             "metric": metric_name, "value": value, "unit": "atom-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -281,8 +300,11 @@ def main():
                                       sizes["B"], sizes["T"], sizes["S"], sizes["A"], sizes["R"], sizes["Mu"], sizes["C"],
                                       ", neighbourhood grades every step" if grade else ""),
                        "atoms": natoms, "potential": os.path.basename(args.potential),
-                       "parallelism": ("domain decomposition %s, RCCL all-to-all halo%s" % (
-                           "x".join(map(str, plan.grid)), ", interior atoms overlap the forward halo" if overlap else ""))
+                       "parallelism": ("domain decomposition %s, %s%s" % (
+                           "x".join(map(str, plan.grid)),
+                           "library halo: grouped RCCL send/recv per direction (communicator of %d ranks, RCCL %d)"
+                           % (halo_info["nranks"], halo_info["rccl_version"]) if halo_info else "torch all-to-all halo (%s)" % backend,
+                           ", rows interior|boundary|interior = %d|%d|%d overlap both exchanges" % (n_a, n_b, n_c) if use_rows else ""))
                        if world > 1 else "single GPU",
                        "atoms_rank0": plan.nlocal, "ghosts_rank0": plan.nghost, "list_entries_rank0": int(plan.first[-1]),
                        "in_cutoff_pairs_rank0": jc_total, "launch": info,

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MTP_MI355X_ABI_VERSION 1
+#define MTP_MI355X_ABI_VERSION 2
 
 /* status codes (the reference aborts through error->one/all, pair_mtp.cpp:92,354-358;
  * the adapter turns a non-zero status + mtp_last_error() into error->all) */
@@ -143,6 +143,17 @@ int mtp_compute(mtp_context *ctx, const double *x, const int *type, int eflag, i
 int mtp_compute_device(mtp_context *ctx, void *stream, const double *d_x, const int *d_type, int eflag,
                        int vflag, int grade_flag, double *d_f, double *d_eatom, double *d_vatom,
                        double *d_ev, double *d_grades, double *d_max_grade, double *d_coeff_ders);
+/* The same on rows [row_begin, row_begin + row_count) of the installed list only (rows = positions in ilist).  A
+ * domain-decomposed step splits its owned atoms into those whose list holds no ghost and the rest, so that the
+ * former are computed while the ghost positions are still in flight (what LAMMPS-KOKKOS does with its
+ * interior / boundary kernels; reference anchor for the semantics: pair_mtp.cpp:252-254, 315).  Energy and virial
+ * keep accumulating in the context's tally slots over the launches of a step; the launch with finish_tallies != 0
+ * folds them into d_ev (the others may pass d_ev = NULL).  Grades / candidate vectors of the rows are produced
+ * per launch. */
+int mtp_compute_device_rows(mtp_context *ctx, void *stream, int row_begin, int row_count, int finish_tallies,
+                            const double *d_x, const int *d_type, int eflag, int vflag, int grade_flag,
+                            double *d_f, double *d_eatom, double *d_vatom, double *d_ev, double *d_grades,
+                            double *d_max_grade, double *d_coeff_ders);
 int mtp_synchronize(mtp_context *ctx, void *stream);
 
 /* PairMTPExtrapolation::calculate_extrapolation_grade (pair_mtp_extrapolation.cpp:347-358)
@@ -153,10 +164,57 @@ int mtp_cfg_grade(const mtp_potential *pot, const double *coeff_ders, double *gr
 /* introspection for benchmarks: LDS bytes per wavefront, wavefronts per workgroup, grid */
 int mtp_context_launch_info(const mtp_context *ctx, int32_t *lds_bytes_per_wave, int32_t *waves_per_block,
                             int32_t *grid_blocks, int32_t *neighbor_tile);
+/* register build the planner chose (2 or 3 wavefronts per SIMD) and whether the per-atom LDS image uses the
+ * "rebuild" layout (radial tables built twice, moments overlaying them) */
+int mtp_context_plan_info(const mtp_context *ctx, int32_t *waves_per_simd, int32_t *rebuild_tables);
 /* last kernel time of the dominant kernel in ms, measured with HIP events on the launch
  * stream (enable with mtp_context_set_timing(ctx, 1); costs one event pair per call) */
 int mtp_context_set_timing(mtp_context *ctx, int enable);
 int mtp_context_last_kernel_ms(mtp_context *ctx, float *ms);
+
+/* ---- multi-GPU halo: spatial domain decomposition, one process per GPU, RCCL over xGMI ------------------------
+ *
+ * The reference leaves the ghost-atom exchange to LAMMPS' Comm class (forward_comm of x before Pair::compute,
+ * reverse_comm of f after it); it only relies on it: forces are written onto ghosts (pair_mtp.cpp:252-254) and
+ * newton_pair must be on (pair_mtp.cpp:315).  A standalone driver (or a KOKKOS-resident LAMMPS that hands over
+ * device views) gets the same two exchanges from the library: device pack / unpack kernels around ONE grouped
+ * RCCL exchange per direction (ncclGroupStart, ncclSend / ncclRecv to every peer, ncclGroupEnd) on the halo's own
+ * stream, ordered with the caller's stream by events, so interior force work overlaps the exchange.
+ *
+ * Layout contract: atoms [0, nlocal) are owned, ghosts follow, grouped by the rank that owns them, in rank order
+ * (recv_counts[q] ghosts from rank q).  send_idx lists, grouped by destination rank in rank order (send_counts[q]
+ * entries for rank q), the owned atoms each peer holds as ghosts, in the order that peer stores them; send_shift
+ * is the periodic shift added to their coordinates on the way.  A rank may be its own peer (periodic images).
+ */
+typedef struct mtp_halo mtp_halo;
+#define MTP_HALO_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+enum { MTP_REDUCE_SUM = 0, MTP_REDUCE_MAX = 1 };
+
+/* ncclGetUniqueId: called on one rank; the caller passes the bytes to every rank (MPI_Bcast, a TCP store, a file) */
+int mtp_halo_get_unique_id(void *id_out /*[MTP_HALO_ID_BYTES]*/);
+/* ncclCommInitRank + device copies of the index lists: collective over all nranks processes */
+int mtp_halo_create(int device_id, int nranks, int rank, const void *unique_id, int nlocal, int nghost,
+                    const int *send_idx /*[sum send_counts]*/, const double *send_shift /*[sum send_counts][3]*/,
+                    const int *send_counts /*[nranks]*/, const int *recv_counts /*[nranks]*/, mtp_halo **out,
+                    char *err, int errlen);
+void mtp_halo_destroy(mtp_halo *halo);
+const char *mtp_halo_last_error(const mtp_halo *halo);
+/* what RCCL itself reports for the communicator (ncclCommCount, ncclCommUserRank, ncclGetVersion) */
+int mtp_halo_comm_count(const mtp_halo *halo, int *nranks, int *rank, int *rccl_version);
+/* Comm::forward_comm: d_x[nlocal + k] <- owner's x + shift.  begin: pack on `stream`, exchange on the halo's
+ * stream; end: `stream` waits for the exchange.  Work queued on `stream` in between overlaps it. */
+int mtp_halo_forward_begin(mtp_halo *halo, void *stream, double *d_x /*[nall][3]*/);
+int mtp_halo_forward_end(mtp_halo *halo, void *stream);
+int mtp_halo_forward(mtp_halo *halo, void *stream, double *d_x);
+/* Comm::reverse_comm: ghost rows of d_f are sent back and added onto their owners (fp64 atomics).  begin: the
+ * exchange starts once `stream` has reached this point (every launch that writes ghost forces must precede it);
+ * end: `stream` waits, then adds the received rows into d_f[0, nlocal). */
+int mtp_halo_reverse_begin(mtp_halo *halo, void *stream, const double *d_f /*[nall][3]*/);
+int mtp_halo_reverse_end(mtp_halo *halo, void *stream, double *d_f);
+int mtp_halo_reverse(mtp_halo *halo, void *stream, double *d_f);
+/* in-place ncclAllReduce of `count` doubles: energy / virial and the configuration-mode candidate vector (SUM,
+ * pair_mtp_extrapolation.cpp:369), the neighbourhood-mode maximum grade (MAX, :379) */
+int mtp_halo_allreduce(mtp_halo *halo, void *stream, double *d_buf, int count, int op);
 
 #ifdef __cplusplus
 }

@@ -24,8 +24,13 @@ EXPORTS = [
     "mtp_set_neighbors", "mtp_set_neighbors_csr", "mtp_set_neighbors_device", "mtp_compute",
     "mtp_compute_device", "mtp_synchronize", "mtp_cfg_grade", "mtp_context_launch_info",
     "mtp_context_set_timing", "mtp_context_last_kernel_ms", "mtp_build_neighbors_device",
-    "mtp_copy_neighbors_to_host",
+    "mtp_copy_neighbors_to_host", "mtp_compute_device_rows", "mtp_context_plan_info",
+    "mtp_halo_get_unique_id", "mtp_halo_create", "mtp_halo_destroy", "mtp_halo_last_error", "mtp_halo_comm_count",
+    "mtp_halo_forward_begin", "mtp_halo_forward_end", "mtp_halo_forward", "mtp_halo_reverse_begin",
+    "mtp_halo_reverse_end", "mtp_halo_reverse", "mtp_halo_allreduce",
 ]
+HALO_ID_BYTES = 128
+REDUCE_SUM, REDUCE_MAX = 0, 1
 
 
 class MtpError(RuntimeError):
@@ -55,14 +60,15 @@ def lib():
         # that same HIP runtime (one runtime per process) instead of loading /opt/rocm's beside it
         import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
-        L.mtp_last_error.restype = C.c_char_p
         for n in EXPORTS:
             getattr(L, n)           # AttributeError if the ABI drifted
         for n in EXPORTS:
-            if n not in ("mtp_last_error", "mtp_potential_free", "mtp_context_destroy"):
-                getattr(L, n).restype = C.c_int
+            getattr(L, n).restype = C.c_int
+        L.mtp_last_error.restype = C.c_char_p
+        L.mtp_halo_last_error.restype = C.c_char_p
         L.mtp_potential_free.restype = None
         L.mtp_context_destroy.restype = None
+        L.mtp_halo_destroy.restype = None
         _lib = L
     return _lib
 
@@ -237,8 +243,22 @@ class Context:
                                              int(bool(grade)), _ptr(f_t), _ptr(eatom_t), _ptr(vatom_t),
                                              _ptr(ev_t), _ptr(grades_t), _ptr(maxg_t), _ptr(coeff_t)))
 
+    def compute_device_rows(self, row_begin, row_count, finish, x_t, type_t, f_t, eflag=0, vflag=0, grade=False,
+                            eatom_t=None, vatom_t=None, ev_t=None, grades_t=None, maxg_t=None, coeff_t=None, stream=None):
+        """Rows [row_begin, row_begin + row_count) of the installed list; `finish` folds the energy / virial tallies."""
+        st = C.c_void_p(stream) if stream else None
+        self._check(lib().mtp_compute_device_rows(self.h, st, int(row_begin), int(row_count), int(bool(finish)),
+                                                  _ptr(x_t), _ptr(type_t), int(eflag), int(vflag), int(bool(grade)),
+                                                  _ptr(f_t), _ptr(eatom_t), _ptr(vatom_t), _ptr(ev_t),
+                                                  _ptr(grades_t), _ptr(maxg_t), _ptr(coeff_t)))
+
     def synchronize(self, stream=None):
         self._check(lib().mtp_synchronize(self.h, C.c_void_p(stream) if stream else None))
+
+    def plan_info(self):
+        a, b = C.c_int32(), C.c_int32()
+        self._check(lib().mtp_context_plan_info(self.h, C.byref(a), C.byref(b)))
+        return dict(waves_per_simd=a.value, rebuild_tables=b.value)
 
     def launch_info(self):
         a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -253,3 +273,71 @@ class Context:
         ms = C.c_float(0)
         self._check(lib().mtp_context_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
+
+
+def halo_unique_id():
+    """ncclGetUniqueId (one rank calls this and hands the bytes to every rank)."""
+    buf = C.create_string_buffer(HALO_ID_BYTES)
+    rc = lib().mtp_halo_get_unique_id(buf)
+    if rc:
+        raise MtpError(rc, "ncclGetUniqueId failed")
+    return buf.raw
+
+
+class Halo:
+    """The library's RCCL halo (include/mtp_mi355x.h, "multi-GPU halo") for one rank of a decomposition
+    (domain.HaloPlan).  Creation is collective over all ranks."""
+
+    def __init__(self, plan, device, unique_id):
+        self.plan = plan
+        self.h = C.c_void_p()
+        idx = np.ascontiguousarray(plan.send_idx, np.int32)
+        shift = np.ascontiguousarray(plan.send_shift, np.float64).reshape(-1, 3)
+        sc = np.ascontiguousarray(plan.send_counts, np.int32)
+        rc_ = np.ascontiguousarray(plan.recv_counts, np.int32)
+        assert len(unique_id) == HALO_ID_BYTES and len(sc) == plan.nranks == len(rc_)
+        err = C.create_string_buffer(512)
+        rc = lib().mtp_halo_create(int(device), int(plan.nranks), int(plan.rank), unique_id, int(plan.nlocal),
+                                   int(plan.nghost), _np(idx, C.c_int), _np(shift, C.c_double), _np(sc, C.c_int),
+                                   _np(rc_, C.c_int), C.byref(self.h), err, 512)
+        if rc:
+            raise MtpError(rc, err.value.decode())
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mtp_halo_destroy(self.h)
+            self.h = None
+
+    def _check(self, rc):
+        if rc:
+            raise MtpError(rc, lib().mtp_halo_last_error(self.h).decode())
+
+    def comm_count(self):
+        n, r, v = C.c_int(), C.c_int(), C.c_int()
+        self._check(lib().mtp_halo_comm_count(self.h, C.byref(n), C.byref(r), C.byref(v)))
+        return dict(nranks=n.value, rank=r.value, rccl_version=v.value)
+
+    @staticmethod
+    def _st(stream):
+        return C.c_void_p(stream) if stream else None
+
+    def forward_begin(self, x_t, stream=None):
+        self._check(lib().mtp_halo_forward_begin(self.h, self._st(stream), _ptr(x_t)))
+
+    def forward_end(self, stream=None):
+        self._check(lib().mtp_halo_forward_end(self.h, self._st(stream)))
+
+    def forward(self, x_t, stream=None):
+        self._check(lib().mtp_halo_forward(self.h, self._st(stream), _ptr(x_t)))
+
+    def reverse_begin(self, f_t, stream=None):
+        self._check(lib().mtp_halo_reverse_begin(self.h, self._st(stream), _ptr(f_t)))
+
+    def reverse_end(self, f_t, stream=None):
+        self._check(lib().mtp_halo_reverse_end(self.h, self._st(stream), _ptr(f_t)))
+
+    def reverse(self, f_t, stream=None):
+        self._check(lib().mtp_halo_reverse(self.h, self._st(stream), _ptr(f_t)))
+
+    def allreduce(self, buf_t, op=REDUCE_SUM, stream=None):
+        self._check(lib().mtp_halo_allreduce(self.h, self._st(stream), _ptr(buf_t), int(buf_t.numel()), int(op)))

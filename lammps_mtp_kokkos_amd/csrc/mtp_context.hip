@@ -63,6 +63,8 @@ struct mtp_context {
   std::string last_error;
   int variant = MTP_VARIANT_AUTO;
   int num_cus = 256;
+  int blob_bytes_norows = 0, blob_bytes_rows = 0;   // LDS table blob without / with the packed times rows
+  bool xcd_map = true;   // MTP_XCD_MAP=0 (tuning override) turns the XCD-aware atom map off
   // potential tables
   DevBuf<double> d_species;
   DevBuf<MtpRow8> d_rows;
@@ -90,6 +92,8 @@ struct mtp_context {
   struct LaunchPlan {
     int wpb = 1, grid = 1, wave_doubles = 0, tab_rows = 0, g_doubles = 0, m_doubles = 0, ov_doubles = 0;
     bool rebuild = false;
+    int wps = 2;
+    bool rows_lds = false;
     size_t lds_bytes = 0;
   } lp[2];   // [0] force calls (wavefront per atom), [1] candidate-vector kernel of grade calls
   DevBuf<double> d_cvec, d_ainv_pad, d_ainv_tiled, d_dbasic;
@@ -115,7 +119,7 @@ void mtp_context::plan()
   (void) mtp_pick_shape(p.alpha_index_basic_count, &KL, &KB);
   const int cap = std::max(64, (max_numneigh + 63) / 64 * 64);
   const size_t LDS = 160 * 1024;
-  const size_t blob = (size_t) base.blob_bytes;
+  size_t blob = (size_t) blob_bytes_norows;   // without the packed rows; a plan adds them when they come for free
   const int nt = 32;
   {   // [0] fused force kernel (also its grade instantiation, which only adds two HBM writes)
     LaunchPlan &L = lp[0];
@@ -123,66 +127,100 @@ void mtp_context::plan()
     L.g_doubles = 0;
     const int d_doubles = A;
     const size_t ints = (size_t) 2 * nt + cap;
-    const int trows = 2 * p.slot_count * MTP_PITCH;   // g and dg rows
-    // coordinate-power rows and moments/adjoints share one overlay (never live together) ...
+    const int grows = p.slot_count * MTP_PITCH;   // g rows; the dg rows take as much again
+    const int trows = 2 * grows;
+    // "keep" layout: [g rows | dg rows | overlay | neighbour arrays]; coordinate-power rows and moments/adjoints share
+    // the overlay (never live together) ...
     const int m_keep = std::max(std::max(A, p.coef_total), 16);   // moments, later the derivative-polynomial coefficients
     const int ov_keep = std::max(3 * P * MTP_PITCH, d_doubles + m_keep);
     const size_t wb_keep = (((size_t) trows + ov_keep + 5 * (size_t) nt) * 8 + ints * 4 + 15) / 16 * 16;
-    // ... and for potentials with many moments the g / dg rows can join the overlay, at the price of building them a
-    // second time ahead of the force phase (the coefficient blocks then sit behind the rows, D[0, B) in front)
+    // ... "rebuild" layout: everything overlays everything.  First table build: g rows and power rows only (the dg rows
+    // are not needed for the moments); moments and adjoints then take the front of the region; ahead of the force
+    // phase the g and dg rows are built again (the coefficient blocks sit behind them, D[0, B) in front).  Costs one
+    // more pass over the neighbours' radial functions, buys LDS: 12.4 instead of 15.7 KB per atom at level 16.
     const int m_reb = std::max(A, 16);
-    const int ov_reb = std::max(trows + std::max(3 * P * MTP_PITCH, p.coef_total), d_doubles + m_reb);
+    const int ov_reb = std::max(std::max(grows + 3 * P * MTP_PITCH, trows + p.coef_total), d_doubles + m_reb);
     const size_t wb_reb = (((size_t) ov_reb + 5 * (size_t) nt) * 8 + ints * 4 + 15) / 16 * 16;
-    // registers allow 8 wavefronts per CU (2 per SIMD at <= 256 VGPRs); MTP_MAX_WAVES overrides for experiments with
-    // builds that cap the kernel at 168 VGPRs (3 per SIMD)
-    int wave_cap = 8;
+    const bool reb_ok = trows >= p.alpha_index_basic_count;
+    // registers: 8 wavefronts per CU (2 per SIMD at <= 256 VGPRs) in workgroups of up to 8, or -- for the table
+    // shapes that have the 168-VGPR build -- 12 (3 per SIMD).  Measured on MI355X: a workgroup is only admitted when
+    // every SIMD it lands on has room, and workgroups of 5..7 wavefronts load the SIMDs unevenly (two 6-wavefront
+    // workgroups never shared a CU at 3 per SIMD); so the 3-per-SIMD plan uses one workgroup of 12 or three of 4.
+    int wave_cap = 32;
     if (const char *e = std::getenv("MTP_MAX_WAVES")) wave_cap = std::max(1, std::min(16, std::atoi(e)));
-    auto max_waves = [&](size_t wbytes) {
-      int best_v = 0;
-      for (int w = 1; w <= MTP_MAX_WPB; w++)
-        if (blob + w * wbytes <= LDS) best_v = std::max(best_v, std::min<int>(wave_cap, (int) (LDS / (blob + w * wbytes)) * w));
-      return best_v;
+    auto waves2 = [&](int w, size_t wbytes) {   // 2-per-SIMD build, w wavefronts per workgroup
+      const size_t blk = blob + w * wbytes;
+      if (w > 8 || blk > LDS) return 0;
+      return std::min<int>(std::min(wave_cap, 8), (int) (LDS / blk) * w);
     };
-    bool rebuild = trows >= p.alpha_index_basic_count && max_waves(wb_reb) > max_waves(wb_keep);
-    if (const char *e = std::getenv("MTP_REBUILD_TABLES"))   // tuning override (benchmarks only)
-      rebuild = std::atoi(e) != 0 && trows >= p.alpha_index_basic_count;
+    auto best2 = [&](size_t wbytes) {
+      int v = 0;
+      for (int w = 1; w <= 8; w++) v = std::max(v, waves2(w, wbytes));
+      return v;
+    };
+    auto shape3 = [&](size_t wbytes) {   // 3-per-SIMD build: wavefronts per workgroup that reach 12 per CU, or 0
+      if (wave_cap < 12) return 0;
+      if (blob + 12 * wbytes <= LDS) return 12;
+      if (3 * (blob + 4 * wbytes) <= LDS) return 4;
+      return 0;
+    };
+    const bool fine = variant == MTP_VARIANT_SMALL || (variant == MTP_VARIANT_AUTO && inum < num_cus * 16);
+    bool rebuild = reb_ok && best2(wb_reb) > best2(wb_keep);
+    int wps = 2, w3 = 0;
+    bool has3 = mtp_wave_kernel_has_wps3(p.fwd_block_count, P) && !fine;
+    if (const char *e = std::getenv("MTP_WPS")) has3 = has3 && std::atoi(e) == 3;   // tuning override (benchmarks only)
+    if (has3 && best2(rebuild ? wb_reb : wb_keep) < 12) {
+      if ((w3 = shape3(wb_keep)) > 0) {
+        wps = 3;
+        rebuild = false;
+      } else if (reb_ok && (w3 = shape3(wb_reb)) > 0) {
+        wps = 3;
+        rebuild = true;
+      }
+    }
+    if (const char *e = std::getenv("MTP_REBUILD_TABLES")) {   // tuning override (benchmarks only)
+      rebuild = std::atoi(e) != 0 && reb_ok;
+      if (wps == 3 && (w3 = shape3(rebuild ? wb_reb : wb_keep)) == 0) wps = 2;
+    }
     L.rebuild = rebuild;
+    L.wps = wps;
     L.m_doubles = rebuild ? m_reb : m_keep;
     L.ov_doubles = rebuild ? ov_reb : ov_keep;
     const size_t wb = rebuild ? wb_reb : wb_keep;
-    // waves per CU for w waves per workgroup; registers allow 8 (2 per SIMD)
-    auto waves_per_cu = [&](int w) {
-      size_t blk = blob + w * wb;
-      if (blk > LDS) return 0;
-      return std::min<int>(wave_cap, (int) (LDS / blk) * w);
-    };
-    // few atoms (or the "small" variant): the finest spread that still reaches the best occupancy;
-    // many atoms: as many wavefronts per workgroup as possible (fewer copies of the table blob)
-    const bool fine = variant == MTP_VARIANT_SMALL || (variant == MTP_VARIANT_AUTO && inum < num_cus * 16);
     int best_w = 0, best = 0;
-    for (int w = 1; w <= MTP_MAX_WPB; w++) {
-      int v = waves_per_cu(w);
-      if (v > best || (v == best && v > 0 && !fine)) {
-        best = v;
-        best_w = w;
-      }
-    }
-    if (best == 0) throw HipFail{hipErrorInvalidValue, "potential + neighbour list exceed one CU's LDS"};
-    if (fine)   // ... but no wider than needed to give every atom its own wavefront
-      for (int w = 1; w < best_w; w++)
-        if ((long long) num_cus * waves_per_cu(w) >= inum) {
+    if (wps == 3) {
+      best_w = w3;
+      best = 12;
+    } else {
+      // few atoms (or the "small" variant): the finest spread that still reaches the best occupancy;
+      // many atoms: as many wavefronts per workgroup as possible (fewer copies of the table blob)
+      for (int w = 1; w <= 8; w++) {
+        int v = waves2(w, wb);
+        if (v > best || (v == best && v > 0 && !fine)) {
+          best = v;
           best_w = w;
-          break;
         }
-    if (const char *e = std::getenv("MTP_WPB")) {   // tuning override (benchmarks only)
-      int v = std::atoi(e);
-      if (v >= 1 && v <= MTP_MAX_WPB && waves_per_cu(v) > 0) best_w = v;
+      }
+      if (best == 0) throw HipFail{hipErrorInvalidValue, "potential + neighbour list exceed one CU's LDS"};
+      if (fine)   // ... but no wider than needed to give every atom its own wavefront
+        for (int w = 1; w < best_w; w++)
+          if ((long long) num_cus * waves2(w, wb) >= inum) {
+            best_w = w;
+            break;
+          }
+      if (const char *e = std::getenv("MTP_WPB")) {   // tuning override (benchmarks only)
+        int v = std::atoi(e);
+        if (v >= 1 && v <= 8 && waves2(v, wb) > 0) best_w = v;
+      }
+      best = std::max(1, waves2(best_w, wb));
     }
-    best = std::max(1, waves_per_cu(best_w));
+    const int blocks_per_cu = std::max(1, best / best_w);
+    // packed times rows in LDS when the chosen shape still fits with them (or when they are tiny)
+    L.rows_lds = (size_t) blocks_per_cu * ((size_t) blob_bytes_rows + best_w * wb) <= LDS;
+    if (const char *e = std::getenv("MTP_ROWS_LDS")) L.rows_lds = L.rows_lds && std::atoi(e) != 0;   // tuning override
     L.wpb = best_w;
     L.wave_doubles = (int) (wb / 8);
-    L.lds_bytes = blob + wb * best_w;
-    const int blocks_per_cu = std::max(1, best / best_w);
+    L.lds_bytes = (L.rows_lds ? (size_t) blob_bytes_rows : blob) + wb * best_w;
     const int need = (inum + best_w - 1) / best_w;
     L.grid = std::max(1, std::min(need, num_cus * blocks_per_cu));
   }
@@ -313,6 +351,7 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     c->pot = pot;
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount;
+    if (const char *e = std::getenv("MTP_XCD_MAP")) c->xcd_map = std::atoi(e) != 0;
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     hipStream_t st = c->stream;
     c->d_species.upload(pot->species_coeffs, st);
@@ -336,22 +375,9 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     c->d_rows.upload(rows8.data(), rows8.size(), st);
     // table blob copied into LDS by every workgroup
     MtpDevParams &bb = c->base;
-    // The packed rows stay in HBM/L2 unless they are tiny: measured cost at level 16 is < 1 % (row
-    // reads do not depend on data), and without them in every workgroup's LDS one more wavefront fits per CU.
-    bb.rows_in_lds = rows8.size() * sizeof(MtpRow8) <= 1024;
-    {   // ... or when they fit next to 8 wavefronts' private regions anyway (measured 1.2 % faster at level 16);
-        // estimate with the usual list (<= 128 entries per row, 32-neighbour tile) -- plan() has the last word on
-        // the workgroup shape, this only decides where the rows live
-      const int A_ = pot->alpha_moment_count, P_ = pot->max_alpha_index_basic;
-      const size_t dbl = (size_t) 2 * pot->slot_count * MTP_PITCH + std::max(3 * P_ * MTP_PITCH, A_ + std::max(std::max(A_, pot->coef_total), 16)) + 5 * 32;
-      const size_t wb = (dbl * 8 + (64 + 128) * 4 + 15) / 16 * 16;
-      const size_t others = 8192;   // the rest of the blob, generously
-      if (8 * wb + others + rows8.size() * sizeof(MtpRow8) <= 160 * 1024) bb.rows_in_lds = 1;
-    }
-    if (const char *e = std::getenv("MTP_ROWS_LDS")) {   // tuning override (benchmarks only)
-      if (std::atoi(e) == 0) bb.rows_in_lds = 0;
-      else if (rows8.size() * sizeof(MtpRow8) <= 24 * 1024) bb.rows_in_lds = 1;
-    }
+    // The packed rows are the LAST piece of the blob: a launch plan copies them into LDS (blob_bytes_rows) or leaves
+    // them in HBM/L2 (blob_bytes_norows) -- measured at level 16: rows in LDS are 1.2 % faster when they fit beside
+    // the wavefronts' private regions anyway, and < 1 % slower otherwise (row reads do not depend on data).
     std::vector<unsigned char> blob;
     auto put = [&](const void *src, size_t bytes) {
       size_t off = (blob.size() + 15) / 16 * 16;
@@ -359,7 +385,6 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
       if (bytes) std::memcpy(blob.data() + off, src, bytes);
       return (int) off;
     };
-    bb.off_rows = bb.rows_in_lds ? put(rows8.data(), rows8.size() * sizeof(MtpRow8)) : 0;
     bb.off_level = put(pot->level_offset.data(), pot->level_offset.size() * sizeof(int32_t));
     std::vector<int32_t> slot_pad((size_t) pot->radial_func_count * MTP_PSTRIDE, -1);
     for (int mu = 0; mu < pot->radial_func_count; mu++)
@@ -392,7 +417,12 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     bb.off_fwd = put(pot->fwd_blocks.data(), pot->fwd_blocks.size() * sizeof(int32_t));
     bb.nfb = pot->fwd_block_count;
     blob.resize((blob.size() + 15) / 16 * 16, 0);
-    bb.blob_bytes = (int) blob.size();
+    c->blob_bytes_norows = (int) blob.size();
+    bb.off_rows = put(rows8.data(), rows8.size() * sizeof(MtpRow8));
+    blob.resize((blob.size() + 15) / 16 * 16, 0);
+    c->blob_bytes_rows = (int) blob.size();
+    bb.blob_bytes = c->blob_bytes_norows;   // plan() decides per launch plan
+    bb.rows_in_lds = 0;
     c->d_blob.upload(blob.data(), blob.size(), st);
     if (pot->has_selection) {   // inverse active set zero padded to a multiple of 16 for the MFMA grade kernel
       const int C = pot->coeff_count;
@@ -664,11 +694,16 @@ int mtp_copy_neighbors_to_host(mtp_context *c, int *first, int *neigh)
   return MTP_OK;
 }
 
-int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const int *d_type, int eflag, int vflag,
-                       int grade_flag, double *d_f, double *d_eatom, double *d_vatom, double *d_ev,
-                       double *d_grades, double *d_max_grade, double *d_coeff_ders)
+int mtp_compute_device_rows(mtp_context *c, void *stream, int row_begin, int row_count, int finish_tallies,
+                            const double *d_x, const int *d_type, int eflag, int vflag, int grade_flag, double *d_f,
+                            double *d_eatom, double *d_vatom, double *d_ev, double *d_grades, double *d_max_grade,
+                            double *d_coeff_ders)
 {
   if (!c) return MTP_ERR_ARG;
+  if (row_begin < 0 || row_count < 0 || (c->have_list && row_begin + row_count > c->inum)) {
+    c->last_error = "row range outside the neighbour list";
+    return MTP_ERR_ARG;
+  }
   if (!c->have_list) {
     c->last_error = "mtp_compute before mtp_set_neighbors";
     return MTP_ERR_STATE;
@@ -693,7 +728,7 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
       return MTP_ERR_LIMIT;
     }
   }
-  if (((eflag & MTP_ENERGY_GLOBAL) || vflag) && !d_ev) return MTP_ERR_ARG;
+  if (((eflag & MTP_ENERGY_GLOBAL) || vflag) && finish_tallies && !d_ev) return MTP_ERR_ARG;
   if (c->inum == 0) return MTP_OK;
   if (hipSetDevice(c->device) != hipSuccess) {
     c->last_error = "hipSetDevice failed";
@@ -701,7 +736,8 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
   }
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
   MtpDevParams p = c->base;
-  p.inum = c->inum;
+  p.inum = row_count;      // rows of THIS launch: [row0, row0 + inum) of the installed list
+  p.row0 = row_begin;
   p.nall = c->nall;
   p.ilist = c->ilist;
   p.first = c->first;
@@ -714,15 +750,23 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
   p.eflag = eflag;
   p.vflag = vflag;
   p.grade_flag = grade_flag ? 1 : 0;
-  {
-    static const bool xcd_on = [] { const char *e = std::getenv("MTP_XCD_MAP"); return !e || std::atoi(e) != 0; }();
-    p.xcd_map = xcd_on && c->inum >= 8 * 64 ? 1 : 0;   // tuning override: MTP_XCD_MAP=0
-  }
+  p.xcd_map = c->xcd_map && row_count >= 8 * 64 ? 1 : 0;
   const mtp_context::LaunchPlan &L = c->lp[0];
+  // the planned grid covers the whole list; a row range needs no more workgroups than it has wavefronts' worth of rows
+  // (kept a multiple of 8 where possible: the XCD-aware atom map wants whole rounds of the 8 XCDs)
+  auto grid_for = [&](const mtp_context::LaunchPlan &lp_) {
+    int g = std::min(lp_.grid, (row_count + lp_.wpb - 1) / lp_.wpb);
+    if (g >= 8) g = std::min(lp_.grid, (g + 7) / 8 * 8);
+    return std::max(1, g);
+  };
   p.tab_rows = L.tab_rows;
   p.m_doubles = L.m_doubles;
   p.ov_doubles = L.ov_doubles;
   p.rebuild_tables = L.rebuild ? 1 : 0;
+  p.rows_in_lds = L.rows_lds ? 1 : 0;
+  p.blob_bytes = L.rows_lds ? c->blob_bytes_rows : c->blob_bytes_norows;
+  p.pow_row = (L.rebuild ? 1 : 2) * c->pot->slot_count;
+  p.wps = L.wps;
   p.wave_doubles = L.wave_doubles;
   p.cvec = grade_flag ? c->d_cvec.ptr : nullptr;
   p.cpad = c->cpad;
@@ -741,30 +785,43 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
       }
       HIP_CHECK(hipEventRecord(c->ev0, st));
     }
-    HIP_CHECK(mtp_launch_wave_kernel(p, L.grid, L.wpb, L.lds_bytes, st));
+    if (row_count > 0) HIP_CHECK(mtp_launch_wave_kernel(p, grid_for(L), L.wpb, L.lds_bytes, st));
     if (c->timing) {
       HIP_CHECK(hipEventRecord(c->ev1, st));
       c->timed = true;
     }
-    if ((eflag & MTP_ENERGY_GLOBAL) || vflag) HIP_CHECK(mtp_launch_ev_finish(c->d_ev_slots.ptr, d_ev, st));
-    if (grade_flag) {
+    // the per-wavefront tally slots keep accumulating over the launches of a step; the last one folds them
+    if (finish_tallies && ((eflag & MTP_ENERGY_GLOBAL) || vflag)) HIP_CHECK(mtp_launch_ev_finish(c->d_ev_slots.ptr, d_ev, st));
+    if (grade_flag && row_count > 0) {
       if (!fused) {
         MtpDevParams pc = p;   // radial block of the candidate vectors from the adjoints left in HBM
+        pc.blob_bytes = c->blob_bytes_norows;
+        pc.rows_in_lds = 0;
         pc.wave_doubles = c->lp[1].wave_doubles;
         pc.tab_rows = c->lp[1].tab_rows;
-        HIP_CHECK(mtp_launch_cvec_kernel(pc, c->lp[1].grid, c->lp[1].wpb, c->lp[1].lds_bytes, st));
+        HIP_CHECK(mtp_launch_cvec_kernel(pc, grid_for(c->lp[1]), c->lp[1].wpb, c->lp[1].lds_bytes, st));
       }
+      const double *cv = c->d_cvec.ptr + (size_t) row_begin * c->cpad;
       if (cfg)
-        HIP_CHECK(mtp_launch_colsum_kernel(c->d_cvec.ptr, c->cpad, c->pot->coeff_count, c->inum, d_coeff_ders, st));
+        HIP_CHECK(mtp_launch_colsum_kernel(cv, c->cpad, c->pot->coeff_count, row_count, d_coeff_ders, st));
       else
-        HIP_CHECK(mtp_launch_grade_kernel(c->d_cvec.ptr, c->d_ainv_pad.ptr, c->d_ainv_tiled.ptr, c->cpad, c->pot->coeff_count, c->inum,
-                                          c->ilist, d_grades, d_max_grade, st));
+        HIP_CHECK(mtp_launch_grade_kernel(cv, c->d_ainv_pad.ptr, c->d_ainv_tiled.ptr, c->cpad, c->pot->coeff_count, row_count,
+                                          c->ilist + row_begin, d_grades, d_max_grade, st));
     }
   } catch (const HipFail &f) {
     c->last_error = std::string(f.what) + ": " + hipGetErrorString(f.e);
     return MTP_ERR_DEVICE;
   }
   return MTP_OK;
+}
+
+int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const int *d_type, int eflag, int vflag,
+                       int grade_flag, double *d_f, double *d_eatom, double *d_vatom, double *d_ev,
+                       double *d_grades, double *d_max_grade, double *d_coeff_ders)
+{
+  if (!c) return MTP_ERR_ARG;
+  return mtp_compute_device_rows(c, stream, 0, c->inum, 1, d_x, d_type, eflag, vflag, grade_flag, d_f, d_eatom, d_vatom,
+                                 d_ev, d_grades, d_max_grade, d_coeff_ders);
 }
 
 int mtp_synchronize(mtp_context *c, void *stream)
@@ -866,6 +923,14 @@ int mtp_context_launch_info(const mtp_context *c, int32_t *lds_bytes_per_wave, i
   if (waves_per_block) *waves_per_block = L.wpb;
   if (grid_blocks) *grid_blocks = L.grid;
   if (neighbor_tile) *neighbor_tile = c->base.NT;
+  return MTP_OK;
+}
+
+int mtp_context_plan_info(const mtp_context *c, int32_t *waves_per_simd, int32_t *rebuild_tables)
+{
+  if (!c || !c->have_list) return MTP_ERR_STATE;
+  if (waves_per_simd) *waves_per_simd = c->lp[0].wps;
+  if (rebuild_tables) *rebuild_tables = c->lp[0].rebuild ? 1 : 0;
   return MTP_OK;
 }
 

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(512, 2) mtp_cvec_kernel(const MtpDevParams p)
   unsigned pdk = addr(DK + kl);
   asm volatile("" : "+v"(pdk));
 
-  for (int ii = blockIdx.x * wpb + wave; ii < p.inum; ii += gridDim.x * wpb) {
+  for (int ii = p.row0 + blockIdx.x * wpb + wave; ii < p.row0 + p.inum; ii += gridDim.x * wpb) {
     const int i = __builtin_amdgcn_readfirstlane(p.ilist[ii]);
     const int itype = __builtin_amdgcn_readfirstlane(p.type[i] - 1);
     if (itype < 0 || itype >= p.Sp) continue;   // reported by the force kernel

@@ -7,7 +7,7 @@
 #include <cstdint>
 
 #define MTP_EV_SLOTS 1024   // per-wave energy/virial tally slots (8 doubles each)
-#define MTP_MAX_WPB 8       // wavefronts per workgroup (512 threads)
+#define MTP_MAX_WPB 12      // wavefronts per workgroup: 8 (512 threads) in the 2-per-SIMD build, 12 in the 3-per-SIMD build
 #define MTP_PITCH 33        // doubles per row of the per-wavefront LDS tables (32 neighbour columns + 1: odd pitch)
 #define MTP_PSTRIDE 12      // slot ids per mu in the LDS blob (nu = 0..11, -1 padded)
 
@@ -74,7 +74,11 @@ struct MtpDevParams {
   // launch geometry
   int NT;                  // neighbours per LDS tile: 32 (table row pitch MTP_PITCH doubles)
   int tab_rows;            // table rows = 2*nslot + 3*P (candidate-vector kernel: 4*P + R)
-  int rebuild_tables;      // moments / adjoints also overlay the g, dg rows; the rows are rebuilt ahead of the force phase
+  int rebuild_tables;      // moments / adjoints also overlay the g, dg rows; the first table build leaves out the dg rows and
+                           // the rows are built a second time (g and dg) ahead of the force phase
+  int pow_row;             // first coordinate-power row of the table: 2*nslot, or nslot when rebuild_tables
+  int wps;                 // register build: 2 or 3 wavefronts per SIMD (mtp_wave_kernel's WPS)
+  int row0;                // first row of ilist / first this launch works on (inum = rows of this launch)
   int ov_doubles;          // force kernel: doubles of the overlay = max(3*P*MTP_PITCH, m_doubles + d_doubles)
   int cj_cap;              // capacity of the compacted id list
   int wave_doubles;        // LDS doubles per wavefront
@@ -88,6 +92,7 @@ int mtp_pick_shape(int B, int *KL, int *KB);
 // lane-grid shape of the force kernel's basic-moment pass: KL lanes x NB 3x3 blocks per lane; -1 beyond 256 blocks
 int mtp_pick_fwd_shape(int nblk, int *KL, int *NB);
 hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);
+bool mtp_wave_kernel_has_wps3(int nfb, int P);
 hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st);
 // radial block of cvec from dbasic (grade calls, after the force kernel)
 hipError_t mtp_launch_cvec_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);

@@ -108,7 +108,7 @@ template <int PITCH> struct WaveLds {
 // neighbour-group count with dummy neighbours sitting exactly on the cutoff (g = dg = 0).
 template <int PITCH>
 __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const WaveLds<PITCH> &w,
-                                           int t0, int cnt, int ntp, bool gather, bool powers, double xi0,
+                                           int t0, int cnt, int ntp, bool gather, bool powers, bool with_dg, double xi0,
                                            double xi1, double xi2, int i, int itype, int lane)
 {
   if (gather) {
@@ -176,7 +176,7 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
             const double g = val * rp;
             if (sidx >= 0) {
               col[sidx * PITCH] = g;                                       // f_mu / r^nu
-              col[(kp->nslot + sidx) * PITCH] = der * rp - nu * g * inv;     // d/dr (f_mu / r^nu)
+              if (with_dg) col[(kp->nslot + sidx) * PITCH] = der * rp - nu * g * inv;     // d/dr (f_mu / r^nu)
             }
             rp *= inv;
           }
@@ -209,7 +209,7 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
           const double g = val * rp;
           if (sidx >= 0) {
             col[sidx * PITCH] = g;
-            col[(kp->nslot + sidx) * PITCH] = der * rp - nu * g * inv;
+            if (with_dg) col[(kp->nslot + sidx) * PITCH] = der * rp - nu * g * inv;
           }
           rp *= inv;
         }
@@ -217,7 +217,7 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
     }
     if (powers) {   // rows of one axis: [q] = u^q
       const double u0 = h == 0 ? w.nbx[n] : w.nbz[n];
-      double *pc = col + (size_t) (2 * kp->nslot + (h == 0 ? 0 : 2 * P)) * PITCH;
+      double *pc = col + (size_t) (kp->pow_row + (h == 0 ? 0 : 2 * P)) * PITCH;
       double cur = 1.0;
       pc[0] = 1.0;
       for (int q = 1; q < P; q++) {
@@ -390,11 +390,10 @@ __device__ __forceinline__ void force_degree(KP kp, unsigned pcol, unsigned pcoe
   }
 }
 
-#ifndef MTP_WAVES_PER_SIMD
-#define MTP_WAVES_PER_SIMD 2
-#endif
-template <int KL, int NB, int PITCH, bool GRADE, int DEG>
-__global__ void __launch_bounds__(512, MTP_WAVES_PER_SIMD) mtp_wave_kernel(const MtpDevParams p_arg)
+// WPS = wavefronts per SIMD the register budget is sized for: 2 (<= 256 VGPRs, workgroups of up to 8 wavefronts) or
+// 3 (<= 168 VGPRs, workgroups of up to 12: one workgroup per CU puts three wavefronts on every SIMD)
+template <int KL, int NB, int PITCH, bool GRADE, int DEG, int WPS>
+__global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(const MtpDevParams p_arg)
 {
   constexpr int NT = 32;                 // neighbours per tile
   constexpr int NG = 64 / KL;            // neighbour groups in the wavefront
@@ -449,9 +448,9 @@ __global__ void __launch_bounds__(512, MTP_WAVES_PER_SIMD) mtp_wave_kernel(const
 #pragma unroll
     for (int h = 0; h < 3; h++) {
       hg[t][h] = w.addr(w.tab + (size_t) ((w0 >> (8 * h)) & 255u) * PITCH + q);
-      hx[t][h] = w.addr(w.tab + (size_t) (2 * ns + ((w1 >> (4 * h)) & 15u)) * PITCH + q);
-      ty[t][h] = w.addr(w.tab + (size_t) (2 * ns + P + ((w1 >> (12 + 4 * h)) & 15u)) * PITCH + q);
-      tz[t][h] = w.addr(w.tab + (size_t) (2 * ns + 2 * P + ((w2 >> (4 * h)) & 15u)) * PITCH + q);
+      hx[t][h] = w.addr(w.tab + (size_t) (kp->pow_row + ((w1 >> (4 * h)) & 15u)) * PITCH + q);
+      ty[t][h] = w.addr(w.tab + (size_t) (kp->pow_row + P + ((w1 >> (12 + 4 * h)) & 15u)) * PITCH + q);
+      tz[t][h] = w.addr(w.tab + (size_t) (kp->pow_row + 2 * P + ((w2 >> (4 * h)) & 15u)) * PITCH + q);
       // one finished address per register: stops the optimiser from re-splitting them into
       // base + row offset (which costs a v_add per LDS read in the inner loops)
       asm volatile("" : "+v"(hg[t][h]), "+v"(hx[t][h]), "+v"(ty[t][h]), "+v"(tz[t][h]));
@@ -471,12 +470,12 @@ __global__ void __launch_bounds__(512, MTP_WAVES_PER_SIMD) mtp_wave_kernel(const
   int ii_beg, ii_end, ii_step;
   if (kp->xcd_map && (gridDim.x & 7) == 0) {
     const int chunk = (kp->inum + 7) >> 3, xcd = blockIdx.x & 7;
-    ii_beg = xcd * chunk + (blockIdx.x >> 3) * wpb + wave;
-    ii_end = min(kp->inum, (xcd + 1) * chunk);
+    ii_beg = kp->row0 + xcd * chunk + (blockIdx.x >> 3) * wpb + wave;
+    ii_end = kp->row0 + min(kp->inum, (xcd + 1) * chunk);
     ii_step = (gridDim.x >> 3) * wpb;
   } else {
-    ii_beg = blockIdx.x * wpb + wave;
-    ii_end = kp->inum;
+    ii_beg = kp->row0 + blockIdx.x * wpb + wave;
+    ii_end = kp->row0 + kp->inum;
     ii_step = gridDim.x * wpb;
   }
   for (int ii = ii_beg; ii < ii_end; ii += ii_step) {
@@ -579,7 +578,7 @@ __global__ void __launch_bounds__(512, MTP_WAVES_PER_SIMD) mtp_wave_kernel(const
     const int ntiles = (cnt + NT - 1) / NT;
     for (int tile = 0; tile < ntiles; tile++) {
       const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-      build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, tile > 0, true, xi0, xi1, xi2, i, itype, lane);
+      build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, tile > 0, true, !kp->rebuild_tables, xi0, xi1, xi2, i, itype, lane);
       STAMP(2);   // tile tables
     KP_FRESH();
 #pragma unroll
@@ -724,7 +723,7 @@ __global__ void __launch_bounds__(512, MTP_WAVES_PER_SIMD) mtp_wave_kernel(const
       for (int tile = 0; tile < ntiles; tile++) {
         const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
         if (ntiles > 1 || kp->rebuild_tables)
-          build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, ntiles > 1, false, xi0, xi1, xi2, i, itype, lane);
+          build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, ntiles > 1, false, true, xi0, xi1, xi2, i, itype, lane);
         // columns past ntp hold stale (finite or not) data: their lanes are masked at the end
         const double x = w.nbx[n], y = w.nby[n], z = w.nbz[n], inv = w.nbi[n];
         double UA = 0.0, VA = 0.0, UB = 0.0, VB = 0.0, S0 = 0.0;
@@ -1029,36 +1028,47 @@ __global__ void __launch_bounds__(256) mtp_colsum_kernel(const double *__restric
   unsafeAtomicAdd(&coeff_ders[c], s);
 }
 
-template <int KL, int NB, int PITCH, bool GRADE, int DEG>
+template <int KL, int NB, int PITCH, bool GRADE, int DEG, int WPS>
 hipError_t launch_one(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
 {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mtp_wave_kernel<KL, NB, PITCH, GRADE, DEG>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  // the dynamic-LDS limit is a per-device attribute of the function: one bit per device id
+  static unsigned long long attr_mask = 0;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev > 63 || !((attr_mask >> dev) & 1ull)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mtp_wave_kernel<KL, NB, PITCH, GRADE, DEG, WPS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (dev >= 0 && dev <= 63) attr_mask |= 1ull << dev;
   }
-  hipLaunchKernelGGL((mtp_wave_kernel<KL, NB, PITCH, GRADE, DEG>), dim3(grid), dim3(64 * wpb), lds, st, p);
+  hipLaunchKernelGGL((mtp_wave_kernel<KL, NB, PITCH, GRADE, DEG, WPS>), dim3(grid), dim3(64 * wpb), lds, st, p);
   return hipGetLastError();
 }
 
-template <int KL, int NB, int DEG> hipError_t launch_grade(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
+template <int KL, int NB, int DEG, int WPS>
+hipError_t launch_grade(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
 {
   // only the 32-neighbour tile (pitch MTP_PITCH) is instantiated; the grade variant is its own instantiation so the
   // force-only kernel keeps its register budget
-  return p.grade_flag ? launch_one<KL, NB, MTP_PITCH, true, DEG>(p, grid, wpb, lds, st)
-                      : launch_one<KL, NB, MTP_PITCH, false, DEG>(p, grid, wpb, lds, st);
+  return p.grade_flag ? launch_one<KL, NB, MTP_PITCH, true, DEG, WPS>(p, grid, wpb, lds, st)
+                      : launch_one<KL, NB, MTP_PITCH, false, DEG, WPS>(p, grid, wpb, lds, st);
 }
 
 // DEG = highest tensor rank the unrolled force phase covers (monomials up to degree DEG-1 in registers):
 // narrow lane grids come with ranks <= 6 in the MLIP level tables, wide ones with ranks <= 8;
-// DEG = 11 is the general instantiation (the loader caps the rank at 11).
+// DEG = 11 is the general instantiation (the loader caps the rank at 11).  The 168-VGPR build (three wavefronts per
+// SIMD) exists for the narrow grids with ranks <= 6 -- the shapes whose per-atom LDS image lets twelve wavefronts
+// share a CU (mtp_wave_kernel_has_wps3() tells the planner).
 template <int KL, int NB> hipError_t launch_pitch(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
 {
   constexpr int DLOW = KL <= 32 ? 6 : 8;
-  if (p.P - 1 <= DLOW) return launch_grade<KL, NB, DLOW>(p, grid, wpb, lds, st);
-  return launch_grade<KL, NB, 11>(p, grid, wpb, lds, st);
+  if (p.P - 1 <= DLOW) {
+    if constexpr (KL <= 32 && NB == 1)
+      if (p.wps == 3) return launch_grade<KL, NB, DLOW, 3>(p, grid, wpb, lds, st);
+    return launch_grade<KL, NB, DLOW, 2>(p, grid, wpb, lds, st);
+  }
+  return launch_grade<KL, NB, 11, 2>(p, grid, wpb, lds, st);
 }
 
 }   // namespace
@@ -1102,10 +1112,18 @@ int mtp_pick_fwd_shape(int nblk, int *KL, int *NB)
   return -1;
 }
 
+// whether the three-wavefronts-per-SIMD build exists for this table shape (see launch_pitch)
+bool mtp_wave_kernel_has_wps3(int nfb, int P)
+{
+  int KL = 0, NB = 0;
+  return mtp_pick_fwd_shape(nfb, &KL, &NB) == 0 && KL <= 32 && NB == 1 && P - 1 <= 6;
+}
+
 hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st)
 {
   int KL = 0, NB = 0;
   if (mtp_pick_fwd_shape(p.nfb, &KL, &NB) != 0 || p.NT != 32) return hipErrorInvalidValue;
+  if (wpb < 1 || wpb > (p.wps == 3 ? 12 : 8)) return hipErrorInvalidValue;
 #define MTP_CASE(kl, nb) \
   if (KL == kl && NB == nb) return launch_pitch<kl, nb>(p, grid, wpb, lds, st);
   MTP_CASE(16, 1)

@@ -5,11 +5,14 @@ force call is bracketed by a forward halo (ghost positions) and a reverse halo (
 forces summed into their owners: `newton_pair on`,
 /root/reference/LAMMPS/ML-MTP/pair_mtp.cpp:252-254, 315).
 
-One process per GPU.  The exchange is ONE `all_to_all_single` each way (RCCL on GPUs:
-grouped send/recv to every peer at once, so on a fully connected xGMI node all 7 links
-carry traffic concurrently and there is a single latency stage instead of LAMMPS'
-x -> y -> z staging; `gloo` on CPU for tests).  Energies/virials stay rank-local sums
-until the caller all-reduces them, as LAMMPS does at thermo output.
+One process per GPU.  This module holds the *plan* (who owns what, which ghosts, index
+lists) and a torch twin of the exchange, `HaloExchange`, used by the CPU tests (`gloo`) and
+the several-ranks-on-one-GPU rehearsals.  On MI355X nodes the exchange itself is the
+library's: `capi.Halo` -> `mtp_halo_*` (csrc/mtp_halo.hip: device pack / unpack kernels and
+ONE grouped RCCL send/recv per direction, so on a fully connected xGMI node all 7 links carry
+traffic concurrently and there is a single latency stage instead of LAMMPS' x -> y -> z
+staging).  Energies/virials stay rank-local sums until the caller all-reduces them, as
+LAMMPS does at thermo output.
 """
 from __future__ import annotations
 
@@ -222,3 +225,15 @@ def sub_list(plan: HaloPlan, rows):
     else:
         neigh = np.zeros(0, dtype=np.int32)
     return plan.ilist[rows].astype(np.int32), first, neigh.astype(np.int32)
+
+
+def overlap_order(plan: HaloPlan, frac_first=0.5):
+    """Neighbour list of the rank reordered for an overlapped step: rows [0, nA) and [nA + nB, nA + nB + nC) are
+    interior atoms (no ghost in their list), rows [nA, nA + nB) the boundary atoms.  The step then runs
+    forward-halo || rows A, boundary rows, reverse-halo || rows C (mtp_compute_device_rows).
+    Returns (ilist, first, neigh, (nA, nB, nC))."""
+    interior, boundary = split_interior(plan)
+    na = int(len(interior) * frac_first)
+    order = np.concatenate([interior[:na], boundary, interior[na:]]).astype(np.int64)
+    ilist, first, neigh = sub_list(plan, order)
+    return ilist, first, neigh, (na, len(boundary), len(interior) - na)

@@ -32,7 +32,6 @@ def main():
 
     def forces(plan, split=False):
         """split: interior atoms are computed between forward_begin/forward_end (bench.py's overlap path)"""
-        from lammps_mtp_kokkos_amd.domain import split_interior, sub_list
         st = torch.cuda.current_stream().cuda_stream
         max_nn = int(np.diff(plan.first).max())
         x = torch.from_numpy(plan.x0).to(dev)
@@ -42,19 +41,19 @@ def main():
         f = torch.zeros((plan.nall, 3), dtype=torch.float64, device=dev)
         ev = torch.zeros(8, dtype=torch.float64, device=dev)
         keep = []
-        if split:
-            ctxs = []
-            for rows in split_interior(plan):
-                c = capi.Context(pot, dev.index)
-                t3 = [torch.from_numpy(a).to(dev) for a in sub_list(plan, rows)]
-                c.set_neighbors_device(*t3, plan.nall, max_nn)
-                ctxs.append(c)
-                keep.append(t3)
+        if split:   # bench.py's overlapped step: rows interior | boundary | interior of ONE context
+            from lammps_mtp_kokkos_amd.domain import overlap_order
+            ilist, first, neigh, (na, nb, nc) = overlap_order(plan)
+            ctx = capi.Context(pot, dev.index)
+            t3 = [torch.from_numpy(a).to(dev) for a in (ilist, first, neigh)]
+            keep.append(t3)
+            ctx.set_neighbors_device(*t3, plan.nall, max_nn)
             h = halo.forward_begin(x)
-            ctxs[0].compute_device(x, ty, f, eflag=1, vflag=1, ev_t=ev, stream=st)
+            ctx.compute_device_rows(0, na, False, x, ty, f, eflag=1, vflag=1, stream=st)
             halo.forward_end(h)
-            ctxs[1].compute_device(x, ty, f, eflag=1, vflag=1, ev_t=ev, stream=st)
-            ctxs[1].synchronize(st)
+            ctx.compute_device_rows(na, nb, False, x, ty, f, eflag=1, vflag=1, stream=st)
+            ctx.compute_device_rows(na + nb, nc, True, x, ty, f, eflag=1, vflag=1, ev_t=ev, stream=st)
+            ctx.synchronize(st)
         else:
             ctx = capi.Context(pot, dev.index)
             il, fi, ne = (torch.from_numpy(a).to(dev) for a in (plan.ilist, plan.first, plan.neigh))

@@ -88,3 +88,17 @@ def test_plan_bookkeeping():
             for q, pq in enumerate(plans):
                 assert p.send_counts[q] == pq.recv_counts[r]
             assert (p.send_idx >= 0).all() and (p.send_idx < p.nlocal).all()
+
+
+def test_overlap_order_partitions_rows_into_interior_boundary_interior():
+    from lammps_mtp_kokkos_amd.domain import overlap_order
+    pos, box = mtpgen.bcc_lattice(8, 8, 8)
+    plan = decompose(pos, box, None, 2, 1, 7.0)
+    ilist, first, neigh, (na, nb, nc) = overlap_order(plan)
+    assert na + nb + nc == plan.nlocal and sorted(ilist.tolist()) == list(range(plan.nlocal))
+    for r, i in enumerate(ilist):
+        row = neigh[first[r]:first[r + 1]]
+        want = plan.neigh[plan.first[i]:plan.first[i + 1]]
+        assert np.array_equal(row, want)
+        has_ghost = bool((row >= plan.nlocal).any())
+        assert has_ghost == (na <= r < na + nb)
