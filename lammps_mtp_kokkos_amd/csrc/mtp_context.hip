@@ -89,7 +89,11 @@ struct mtp_context {
   DevBuf<int> d_err;
   DevBuf<unsigned long long> d_stamps;
   // launch geometry
+  struct Layout {   // per-atom LDS image, offsets in doubles (MtpDevParams: dg_mode, pow_row, dg_off, off_*)
+    int mode = 0, pow_row = 0, dg_off = 0, off_m = 0, off_d = 0, off_coef = 0, off_nb = 0, m_doubles = 0;
+  };
   struct LaunchPlan {
+    Layout layout;
     int wpb = 1, grid = 1, wave_doubles = 0, tab_rows = 0, g_doubles = 0, m_doubles = 0, ov_doubles = 0;
     bool rebuild = false;
     int wps = 2;
@@ -129,19 +133,48 @@ void mtp_context::plan()
     const size_t ints = (size_t) 2 * nt + cap;
     const int grows = p.slot_count * MTP_PITCH;   // g rows; the dg rows take as much again
     const int trows = 2 * grows;
-    // "keep" layout: [g rows | dg rows | overlay | neighbour arrays]; coordinate-power rows and moments/adjoints share
-    // the overlay (never live together) ...
-    const int m_keep = std::max(std::max(A, p.coef_total), 16);   // moments, later the derivative-polynomial coefficients
-    const int ov_keep = std::max(3 * P * MTP_PITCH, d_doubles + m_keep);
-    const size_t wb_keep = (((size_t) trows + ov_keep + 5 * (size_t) nt) * 8 + ints * 4 + 15) / 16 * 16;
-    // ... "rebuild" layout: everything overlays everything.  First table build: g rows and power rows only (the dg rows
-    // are not needed for the moments); moments and adjoints then take the front of the region; ahead of the force
-    // phase the g and dg rows are built again (the coefficient blocks sit behind them, D[0, B) in front).  Costs one
-    // more pass over the neighbours' radial functions, buys LDS: 12.4 instead of 15.7 KB per atom at level 16.
+    const size_t tail = 5 * (size_t) nt * 8 + ints * 4;   // neighbour arrays behind the tables
+    // Three layouts of the per-atom LDS image (mtp_kernels.hip, WaveLds), sizes in doubles:
+    //   keep     [g rows | dg rows | overlay]; coordinate-power rows and moments / adjoints share the overlay
+    //            (never live together); the derivative-polynomial coefficients later take the moments' place
+    const int m_keep = std::max(std::max(A, p.coef_total), 16);
+    Layout keep;
+    keep.mode = 0;
+    keep.pow_row = 2 * p.slot_count;
+    keep.dg_off = grows;
+    keep.off_m = trows;
+    keep.off_d = trows + m_keep;
+    keep.off_coef = trows;
+    keep.m_doubles = m_keep;
+    keep.off_nb = trows + std::max(3 * P * MTP_PITCH, d_doubles + m_keep);
+    //   lean     [g rows | overlay]; the dg rows join the overlay behind the coefficient blocks and are written ahead
+    //            of the force phase from radial derivatives the tile build parked in registers (Mu <= 6): 12.4
+    //            instead of 15.7 KB per atom at level 16
+    Layout lean = keep;
+    lean.mode = 1;
+    lean.pow_row = p.slot_count;
+    lean.dg_off = grows + p.coef_total;
+    lean.off_m = grows;
+    lean.off_d = grows + m_keep;
+    lean.off_coef = grows;
+    lean.off_nb = grows + std::max(std::max(3 * P * MTP_PITCH, d_doubles + m_keep), p.coef_total + grows);
+    const bool lean_ok = p.radial_func_count <= 6;
+    //   rebuild  everything overlays everything (many moments): first table build = g rows and power rows only;
+    //            moments and adjoints then take the front of the region; ahead of the force phase the g and dg rows
+    //            are built again (coefficient blocks behind them, D[0, B) in front).  One more pass over the
+    //            neighbours' radial functions buys LDS: level 20 goes from 37 to 24 KB per atom.
     const int m_reb = std::max(A, 16);
-    const int ov_reb = std::max(std::max(grows + 3 * P * MTP_PITCH, trows + p.coef_total), d_doubles + m_reb);
-    const size_t wb_reb = (((size_t) ov_reb + 5 * (size_t) nt) * 8 + ints * 4 + 15) / 16 * 16;
+    Layout reb;
+    reb.mode = 2;
+    reb.pow_row = p.slot_count;
+    reb.dg_off = grows;
+    reb.off_d = 0;
+    reb.off_m = d_doubles;
+    reb.off_coef = trows;
+    reb.m_doubles = m_reb;
+    reb.off_nb = std::max(std::max(grows + 3 * P * MTP_PITCH, trows + p.coef_total), d_doubles + m_reb);
     const bool reb_ok = trows >= p.alpha_index_basic_count;
+    auto bytes_of = [&](const Layout &y) { return ((size_t) y.off_nb * 8 + tail + 15) / 16 * 16; };
     // registers: 8 wavefronts per CU (2 per SIMD at <= 256 VGPRs) in workgroups of up to 8, or -- for the table
     // shapes that have the 168-VGPR build -- 12 (3 per SIMD).  Measured on MI355X: a workgroup is only admitted when
     // every SIMD it lands on has room, and workgroups of 5..7 wavefronts load the SIMDs unevenly (two 6-wavefront
@@ -165,28 +198,42 @@ void mtp_context::plan()
       return 0;
     };
     const bool fine = variant == MTP_VARIANT_SMALL || (variant == MTP_VARIANT_AUTO && inum < num_cus * 16);
-    bool rebuild = reb_ok && best2(wb_reb) > best2(wb_keep);
-    int wps = 2, w3 = 0;
-    bool has3 = mtp_wave_kernel_has_wps3(p.fwd_block_count, P) && !fine;
-    if (const char *e = std::getenv("MTP_WPS")) has3 = has3 && std::atoi(e) == 3;   // tuning override (benchmarks only)
-    if (has3 && best2(rebuild ? wb_reb : wb_keep) < 12) {
-      if ((w3 = shape3(wb_keep)) > 0) {
-        wps = 3;
-        rebuild = false;
-      } else if (reb_ok && (w3 = shape3(wb_reb)) > 0) {
-        wps = 3;
-        rebuild = true;
+    // candidates in order of preference at equal occupancy: keep (no extra work), lean (a few flops), rebuild
+    std::vector<const Layout *> cands = {&keep};
+    if (lean_ok) cands.push_back(&lean);
+    if (reb_ok) cands.push_back(&reb);
+    if (const char *e = std::getenv("MTP_LAYOUT")) {   // tuning override (benchmarks, tests): keep | lean | rebuild
+      const std::string v(e);
+      if (v == "keep") cands = {&keep};
+      else if (v == "lean" && lean_ok) cands = {&lean};
+      else if (v == "rebuild" && reb_ok) cands = {&reb};
+    } else if (const char *e2 = std::getenv("MTP_REBUILD_TABLES")) {   // older spelling of the same override
+      if (std::atoi(e2) != 0 && reb_ok) cands = {&reb};
+      else cands = {&keep};
+    }
+    // the 3-per-SIMD build pays when there are atoms enough to fill twelve wavefronts per CU
+    bool has3 = mtp_wave_kernel_has_wps3(p.fwd_block_count, P);
+    if (const char *e = std::getenv("MTP_WPS")) has3 = has3 && std::atoi(e) == 3;   // tuning override: 2 = never, 3 = whenever it fits
+    else has3 = has3 && !fine;
+    const Layout *pick = nullptr;
+    int wps = 2, w3 = 0, pick_waves = 0;
+    for (const Layout *y : cands) {
+      int v = best2(bytes_of(*y)), vw3 = 0;
+      if (has3 && (vw3 = shape3(bytes_of(*y))) > 0) v = 12;
+      if (v > pick_waves) {
+        pick = y;
+        pick_waves = v;
+        wps = vw3 > 0 ? 3 : 2;
+        w3 = vw3;
       }
     }
-    if (const char *e = std::getenv("MTP_REBUILD_TABLES")) {   // tuning override (benchmarks only)
-      rebuild = std::atoi(e) != 0 && reb_ok;
-      if (wps == 3 && (w3 = shape3(rebuild ? wb_reb : wb_keep)) == 0) wps = 2;
-    }
-    L.rebuild = rebuild;
+    if (!pick) throw HipFail{hipErrorInvalidValue, "potential + neighbour list exceed one CU's LDS"};
+    L.layout = *pick;
+    L.rebuild = pick->mode == 2;
     L.wps = wps;
-    L.m_doubles = rebuild ? m_reb : m_keep;
-    L.ov_doubles = rebuild ? ov_reb : ov_keep;
-    const size_t wb = rebuild ? wb_reb : wb_keep;
+    L.m_doubles = pick->m_doubles;
+    L.ov_doubles = pick->off_nb;
+    const size_t wb = bytes_of(*pick);
     int best_w = 0, best = 0;
     if (wps == 3) {
       best_w = w3;
@@ -765,7 +812,13 @@ int mtp_compute_device_rows(mtp_context *c, void *stream, int row_begin, int row
   p.rebuild_tables = L.rebuild ? 1 : 0;
   p.rows_in_lds = L.rows_lds ? 1 : 0;
   p.blob_bytes = L.rows_lds ? c->blob_bytes_rows : c->blob_bytes_norows;
-  p.pow_row = (L.rebuild ? 1 : 2) * c->pot->slot_count;
+  p.dg_mode = L.layout.mode;
+  p.pow_row = L.layout.pow_row;
+  p.dg_off = L.layout.dg_off;
+  p.w_m = L.layout.off_m;
+  p.w_d = L.layout.off_d;
+  p.w_coef = L.layout.off_coef;
+  p.w_nb = L.layout.off_nb;
   p.wps = L.wps;
   p.wave_doubles = L.wave_doubles;
   p.cvec = grade_flag ? c->d_cvec.ptr : nullptr;

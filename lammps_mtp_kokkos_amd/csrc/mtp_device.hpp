@@ -74,9 +74,13 @@ struct MtpDevParams {
   // launch geometry
   int NT;                  // neighbours per LDS tile: 32 (table row pitch MTP_PITCH doubles)
   int tab_rows;            // table rows = 2*nslot + 3*P (candidate-vector kernel: 4*P + R)
-  int rebuild_tables;      // moments / adjoints also overlay the g, dg rows; the first table build leaves out the dg rows and
-                           // the rows are built a second time (g and dg) ahead of the force phase
-  int pow_row;             // first coordinate-power row of the table: 2*nslot, or nslot when rebuild_tables
+  // per-atom LDS image (mtp_kernels.hip, WaveLds): offsets in doubles from the start of the wavefront's region
+  int dg_mode;             // 0 "keep": dg rows written by the tile build; 1 "lean": written ahead of the force phase from
+                           // radial derivatives parked in registers; 2 "rebuild": g and dg rows built a second time
+  int rebuild_tables;      // dg_mode == 2 (kept for the launch-info report)
+  int pow_row;             // first coordinate-power row of the table: 2*nslot (keep) or nslot
+  int dg_off;              // from a g row to its dg row
+  int w_m, w_d, w_coef, w_nb;   // moments, adjoints, derivative-polynomial coefficients, neighbour arrays
   int wps;                 // register build: 2 or 3 wavefronts per SIMD (mtp_wave_kernel's WPS)
   int row0;                // first row of ilist / first this launch works on (inum = rows of this launch)
   int ov_doubles;          // force kernel: doubles of the overlay = max(3*P*MTP_PITCH, m_doubles + d_doubles)

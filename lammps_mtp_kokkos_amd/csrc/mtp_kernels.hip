@@ -75,24 +75,23 @@ template <int PITCH> struct WaveLds {
   __device__ __forceinline__ unsigned addr(const double *ptr) const { return m_addr + 8u * (unsigned) (ptr - M); }
   __device__ __forceinline__ WaveLds(double *base, unsigned base_addr, KP kp)
   {
-    // [g rows | dg rows | overlay | neighbour arrays]; the overlay holds the coordinate-power rows from
-    // the tile build to the end of the basic-moment pass, and the moments / adjoints (later the
-    // derivative-polynomial coefficients) from there on -- the two are never live together.
-    // Potentials with many moments (rebuild_tables): the moments and adjoints also overlay the g / dg rows, which
-    // are then built a second time ahead of the force phase (the coefficient blocks sit behind the rows, the
-    // adjoints of the basics D[0, B) in front: the host checks that they cannot meet).
+    // Three layouts of the per-atom image, chosen by the host planner (mtp_context.hip, plan()); all of them are
+    // [tables | overlay | neighbour arrays] with the regions placed through offsets in the parameter block:
+    //   keep     [g rows | dg rows | overlay]: the coordinate-power rows live in the overlay from the tile build to the
+    //            end of the basic-moment pass, the moments / adjoints (later the derivative-polynomial coefficients)
+    //            from there on -- the two are never live together;
+    //   lean     [g rows | overlay]: the dg rows join the overlay (behind the coefficient blocks): the tile build keeps
+    //            the radial derivatives f'_mu(r) of its neighbour in registers and the dg rows are written from them
+    //            ahead of the force phase (no second evaluation of the radial functions);
+    //   rebuild  everything overlays everything (potentials with many moments): the moments and adjoints sit on the
+    //            g rows, which are built a second time, with the dg rows, ahead of the force phase (the coefficient
+    //            blocks sit behind the rows, the adjoints of the basics D[0, B) in front: the host checks that they
+    //            cannot meet).
     tab = base;
-    if (kp->rebuild_tables) {
-      D = tab;
-      M = D + kp->d_doubles;
-      coef = tab + (size_t) 2 * kp->nslot * PITCH;
-      nbx = tab + kp->ov_doubles;
-    } else {
-      M = tab + (size_t) 2 * kp->nslot * PITCH;
-      D = M + kp->m_doubles;
-      coef = M;
-      nbx = M + kp->ov_doubles;
-    }
+    M = tab + kp->w_m;
+    D = tab + kp->w_d;
+    coef = tab + kp->w_coef;
+    nbx = tab + kp->w_nb;
     m_addr = base_addr + 8u * (unsigned) (M - tab);
     nby = nbx + NT;
     nbz = nby + NT;
@@ -106,10 +105,13 @@ template <int PITCH> struct WaveLds {
 
 // Phase 2: tables of one tile; columns [0, ntp) are written, ntp = nt rounded up to the
 // neighbour-group count with dummy neighbours sitting exactly on the cutoff (g = dg = 0).
+// with_dg: write the dg rows; park (lean layout, may be null): receives f'_mu(r) of this lane's neighbour for its radial
+// functions mu = h, h + 2, h + 4 (park[0..2]), from which dg_from_parked() writes the dg rows later.
+#define MTP_PARK 3   // radial functions per half-wavefront that can be parked: Mu <= 6
 template <int PITCH>
 __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const WaveLds<PITCH> &w,
-                                           int t0, int cnt, int ntp, bool gather, bool powers, bool with_dg, double xi0,
-                                           double xi1, double xi2, int i, int itype, int lane)
+                                           int t0, int cnt, int ntp, bool gather, bool powers, bool with_dg, double *park,
+                                           double xi0, double xi1, double xi2, int i, int itype, int lane)
 {
   if (gather) {
     if (lane < ntp) {
@@ -155,7 +157,8 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
         qv[ri] = 2.0 * ksi * qv[ri - 1] - qv[ri - 2];
         ev[ri] = 2.0 * (mult * qv[ri - 1] + ksi * ev[ri - 1]) - ev[ri - 2];
       }
-      for (int mu = h; mu < Mu; mu += 2) {
+      for (int mi = 0; 2 * mi + h < Mu; mi++) {
+        const int mu = 2 * mi + h;
         const int4 *sl4 = reinterpret_cast<const int4 *>(bt.slot + mu * MTP_PSTRIDE);
         const int4 sa = sl4[0], sb = sl4[1], sc = sl4[2];
         const int sv[MTP_PSTRIDE] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w, sc.x, sc.y, sc.z, sc.w};
@@ -168,6 +171,11 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
           val = fma(cc[ri], qv[ri], val);
           der = fma(cc[ri], ev[ri], der);
         }
+        if (park) {
+          if (mi == 0) park[0] = der;
+          else if (mi == 1) park[1] = der;
+          else park[2] = der;
+        }
         double rp = 1.0;
 #pragma unroll
         for (int nu = 0; nu < MTP_PSTRIDE; nu++) {
@@ -176,14 +184,15 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
             const double g = val * rp;
             if (sidx >= 0) {
               col[sidx * PITCH] = g;                                       // f_mu / r^nu
-              if (with_dg) col[(kp->nslot + sidx) * PITCH] = der * rp - nu * g * inv;     // d/dr (f_mu / r^nu)
+              if (with_dg) col[kp->dg_off + sidx * PITCH] = der * rp - nu * g * inv;     // d/dr (f_mu / r^nu)
             }
             rp *= inv;
           }
         }
       }
     } else {
-      for (int mu = h; mu < Mu; mu += 2) {
+      for (int mi = 0; 2 * mi + h < Mu; mi++) {
+        const int mu = 2 * mi + h;
         const int *sl = bt.slot + mu * MTP_PSTRIDE;
         const double *c = bt.radial + ((itype * kp->Sp + jt) * Mu + mu) * R;
         double q0 = kp->scaling * (d * d), q1 = kp->scaling * (ksi * d * d);
@@ -203,13 +212,18 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
           e0 = e1;
           e1 = e2;
         }
+        if (park) {
+          if (mi == 0) park[0] = der;
+          else if (mi == 1) park[1] = der;
+          else park[2] = der;
+        }
         double rp = 1.0;
         for (int nu = 0; nu < P; nu++) {
           const int sidx = sl[nu];
           const double g = val * rp;
           if (sidx >= 0) {
             col[sidx * PITCH] = g;
-            if (with_dg) col[(kp->nslot + sidx) * PITCH] = der * rp - nu * g * inv;
+            if (with_dg) col[kp->dg_off + sidx * PITCH] = der * rp - nu * g * inv;
           }
           rp *= inv;
         }
@@ -232,6 +246,39 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
         for (int q = 1; q < P; q++) {
           cur *= u1;
           pc[q * PITCH] = cur;
+        }
+      }
+    }
+  }
+  wave_fence();
+}
+
+// Lean layout, ahead of the force phase: dg rows of the (single) tile from the parked radial derivatives and the g rows
+// that stayed in LDS: d/dr (f_mu / r^nu) = f'_mu / r^nu - nu (f_mu / r^nu) / r, the expression of build_tile().
+template <int PITCH>
+__device__ __forceinline__ void dg_from_parked(KP kp, const BlockTables &bt, const WaveLds<PITCH> &w, int ntp,
+                                               const double *park, int lane)
+{
+  const int n = lane & 31, h = lane >> 5, Mu = kp->Mu, P = kp->P;
+  if (n < ntp) {
+    const double inv = w.nbi[n];
+    double *col = w.tab + n;
+#pragma unroll
+    for (int mi = 0; mi < MTP_PARK; mi++) {
+      const int mu = 2 * mi + h;
+      if (mu < Mu) {
+        const int4 *sl4 = reinterpret_cast<const int4 *>(bt.slot + mu * MTP_PSTRIDE);
+        const int4 sa = sl4[0], sb = sl4[1], sc = sl4[2];
+        const int sv[MTP_PSTRIDE] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w, sc.x, sc.y, sc.z, sc.w};
+        const double der = park[mi];
+        double rp = 1.0;
+#pragma unroll
+        for (int nu = 0; nu < MTP_PSTRIDE; nu++) {
+          if (nu < P) {
+            const int sidx = sv[nu];
+            if (sidx >= 0) col[kp->dg_off + sidx * PITCH] = der * rp - nu * col[sidx * PITCH] * inv;
+            rp *= inv;
+          }
         }
       }
     }
@@ -336,7 +383,7 @@ __device__ __forceinline__ void force_degree(KP kp, unsigned pcol, unsigned pcoe
     if (NU < kp->P) {
       const int s0 = kp->deg_first[NU], cnt = kp->deg_first[NU + 1] - s0;
       const double inv_nu = 1.0 / NU;
-      const unsigned dgo = 8u * (unsigned) (kp->nslot * PITCH);
+      const unsigned dgo = 8u * (unsigned) kp->dg_off;
       const double wa = GRADE ? (part ? z : x) * (rw * inv_nu) : 0.0, wb = GRADE ? y * (rw * inv_nu) : 0.0;
       {
         unsigned ca = pcoef + 8u * (unsigned) (kp->deg_coef[NU] + part * 2 * C);
@@ -431,7 +478,7 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
   const unsigned wave_off = (kp->blob_bytes >> 3) + wave * kp->wave_doubles;   // doubles
   const unsigned lds0 = (unsigned) (size_t) (lds_cdouble *) lds;            // static cast of the array itself
   const WaveLds<PITCH> w(lds + wave_off, lds0 + 8u * wave_off, kp);
-  const int ns = kp->nslot, P = kp->P;
+  const int P = kp->P;
 
   // Basic-moment pass in 3 x 3 register blocks (built on the host, mtp_potential.cpp): lane (q, kl) owns the blocks
   // kl + KL t; a block is 3 heads (slot s, exponent a: head value g_s x^a) times 3 tails (b, c: tail value y^b z^c)
@@ -576,9 +623,11 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
 #pragma unroll
       for (int e = 0; e < 9; e++) acc[t][e] = 0.0;
     const int ntiles = (cnt + NT - 1) / NT;
+    double park[MTP_PARK] = {0.0, 0.0, 0.0};   // lean layout: f'_mu(r) of this lane's neighbour (single-tile atoms)
     for (int tile = 0; tile < ntiles; tile++) {
       const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-      build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, tile > 0, true, !kp->rebuild_tables, xi0, xi1, xi2, i, itype, lane);
+      build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, tile > 0, true, kp->dg_mode == 0, kp->dg_mode == 1 ? park : nullptr, xi0,
+                        xi1, xi2, i, itype, lane);
       STAMP(2);   // tile tables
     KP_FRESH();
 #pragma unroll
@@ -722,15 +771,17 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       double crad = 0.0;
       for (int tile = 0; tile < ntiles; tile++) {
         const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-        if (ntiles > 1 || kp->rebuild_tables)
-          build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, ntiles > 1, false, true, xi0, xi1, xi2, i, itype, lane);
+        if (ntiles > 1 || kp->dg_mode == 2)
+          build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, ntiles > 1, false, true, nullptr, xi0, xi1, xi2, i, itype, lane);
+        else if (kp->dg_mode == 1)
+          dg_from_parked<PITCH>(kp, bt, w, ntp, park, lane);
         // columns past ntp hold stale (finite or not) data: their lanes are masked at the end
         const double x = w.nbx[n], y = w.nby[n], z = w.nbz[n], inv = w.nbi[n];
         double UA = 0.0, VA = 0.0, UB = 0.0, VB = 0.0, S0 = 0.0;
         double Wm[4] = {0.0, 0.0, 0.0, 0.0};
         const bool fused = GRADE && kp->grade_fused;
         {   // rank 0: P_s = D_k, no gradient
-          unsigned cg = pcol + 8u * (unsigned) (ns * PITCH);
+          unsigned cg = pcol + 8u * (unsigned) kp->dg_off;
           for (int sidx = 0; sidx < kp->deg_first[1]; sidx++) {
             const double dk = w.coef[kp->deg_coef[0] + sidx];
             S0 = fma(lds_ld(cg, 0), dk, S0);

@@ -1,5 +1,5 @@
 """Fixed-seed cases of the randomised GPU-vs-oracle sweep (tests/_fuzz.py): random levels, species counts,
-densities (one to three 32-neighbour tiles), ragged subset lists, grade calls, both LDS plans.  Tolerance: 1e-9
+densities (one to three 32-neighbour tiles), ragged subset lists, grade calls, all three LDS layouts.  Tolerance: 1e-9
 relative on forces, energy, virial and grades (fp64 re-association only)."""
 import numpy as np
 import pytest
