@@ -43,6 +43,11 @@ def algorithmic_flops_reference(sizes, jc_total, nlocal):
     return jc_total * (9 + 8 * R + 4 * P + 4 * Mu * R + 34 * B) + nlocal * (9 * T + 2 * S)
 
 
+def info_launch_waves(ctx):
+    i = ctx.launch_info()
+    return i["waves_per_block"] * max(1, i["grid_blocks"] // 256)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,33 +218,32 @@ def main():
     bytes_alg = algorithmic_bytes(int(plan.first[-1]), plan.nall, plan.nlocal)
     flops_ref = algorithmic_flops_reference(sizes, jc_total, plan.nlocal)
     achieved_gbs = bytes_alg / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
+    # rocprofv3 PMC counters of the dominant kernel (scripts/gpu_pmc.sh -> profiles/r02_pmc_counters.json): only quoted when
+    # they were collected from THIS build of the kernels (source hash) on this workload; per launch, like `achieved`
+    traffic, pmc_block = None, None
+    cpath = os.path.join(ROOT, "profiles", "r02_pmc_counters.json")
+    if os.path.exists(cpath) and world == 1:
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            pc = json.load(open(cpath))
+            if pc.get("source_hash") == capi.kernel_source_hash() and pc.get("workload") == args.workload \
+                    and pc.get("cells", 32) == args.cells:
+                cn = pc["counters"]
+                traffic = pc.get("hbm_bytes_per_launch")
+                cyc = kernel_ms * 1e-3 * 2.4e9      # at the 2.4 GHz peak clock: busy fractions are lower bounds
+                ncu = 256
+                pmc_block = {
+                    "source": "profiles/r02_pmc_counters.json (same kernel sources: %s)" % pc["source_hash"][:12],
+                    "lds_busy": cn["SQ_LDS_IDX_ACTIVE"] / ncu / cyc,                    # LDS pipe cycles / kernel cycles, per CU
+                    "lds_bank_conflict_share": cn["SQ_LDS_BANK_CONFLICT"] / max(cn["SQ_LDS_IDX_ACTIVE"], 1.0),
+                    "valu_busy": cn["SQ_INSTS_VALU"] * 4.0 / (4 * ncu) / cyc,           # 4 issue cycles per fp64 wave instruction, 4 SIMDs per CU
+                    "lds_wave_instructions": cn["SQ_INSTS_LDS"], "valu_wave_instructions": cn["SQ_INSTS_VALU"],
+                    "waves_per_cu": info_launch_waves(ctx),
+                }
         except Exception:
-            traffic = None
-    # LDS side of the dominant kernel (its actual bound): wave-level LDS instructions per launch from the committed
-    # rocprofv3 SQ counters of this configuration (profiles/r01_pmc_sq_counters.txt; not collected live), each moving
-    # at most 64 lanes x 8 B, against 128 B/clk/CU x 256 CUs x 2.4 GHz
-    lds_block = None
-    cpath = os.path.join(ROOT, "profiles", "r01_pmc_sq_counters.txt")
-    if os.path.exists(cpath) and args.workload == "w16" and world == 1 and args.cells == 32:
-        try:
-            cnt = {ln.split()[0]: float(ln.split()[1]) for ln in open(cpath) if ln[:1] not in "#\n" and len(ln.split()) == 2}
-            lds_bytes = cnt["SQ_INSTS_LDS"] * 64 * 8
-            peak = 128 * 256 * 2.4e9 / 1e12
-            lds_block = {"achieved": lds_bytes / (kernel_ms * 1e-3) / 1e12, "peak": peak, "unit": "TB/s",
-                         "frac": lds_bytes / (kernel_ms * 1e-3) / 1e12 / peak,
-                         "lds_wave_instructions_per_launch": cnt["SQ_INSTS_LDS"],
-                         "lds_unit_busy_frac_pmc": cnt.get("SQ_LDS_IDX_ACTIVE", 0.0) / 256 / (kernel_ms * 1e-3 * 2.4e9),
-                         "note": "upper bound on bytes (every LDS instruction counted as 64 lanes x 8 B); counters from "
-                                 "profiles/r01_pmc_sq_counters.txt, time measured live"}
-        except Exception:
-            lds_block = None
+            traffic, pmc_block = None, None
 
-    # ---- CPU baseline: the oracle (a port of the reference CPU path), 1 thread, rank 0, N = 1 -----
+    # ---- CPU baseline: the oracle (a port of the reference CPU path), rank 0, N = 1 -----------------
+    # leg (i) one thread; leg (ii) every host core: threads over atoms with private force arrays (oracle/mtp_oracle_mt.c)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.pyoracle import Oracle
@@ -249,16 +253,28 @@ def main():
         sub_first = plan.first[: nsub + 1]
         sub_neigh = plan.neigh[: sub_first[-1]]
         passes, tcpu = 0, 0.0
-        while tcpu < args.cpu_seconds and passes < 50:
+        while tcpu < args.cpu_seconds / 2 and passes < 50:
             c0 = time.perf_counter()
             rc = o.compute(xs, plan.types, plan.ilist[:nsub], sub_first, sub_neigh, eflag=EFLAG, vflag=VFLAG,
                            extrapolation=grade)
             tcpu += time.perf_counter() - c0
             passes += 1
-        cpu = {"value": nsub * passes / tcpu, "unit": "atom-steps/s", "cores": 1, "kind": "port",
+        one = nsub * passes / tcpu
+        cpu = {"value": one, "unit": "atom-steps/s", "cores": 1, "kind": "port",
                "sample": "%d passes over the first %d of the %d atoms (same lattice, potential, list, flags), "
                          "serial C oracle, %.1f s" % (passes, nsub, natoms, tcpu),
                "host_cpus": os.cpu_count()}
+        nthr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        if nthr > 1 and not grade:
+            mp_, tmt = 0, 0.0
+            while tmt < args.cpu_seconds / 2 and mp_ < 200:
+                c0 = time.perf_counter()
+                o.compute_mt(nthr, xs, plan.types, plan.ilist, plan.first, plan.neigh, eflag=EFLAG, vflag=VFLAG)
+                tmt += time.perf_counter() - c0
+                mp_ += 1
+            cpu.update({"value": plan.nlocal * mp_ / tmt, "cores": nthr, "value_1_thread": one,
+                        "sample": "%d passes over all %d atoms, %d threads over atoms with private force arrays "
+                                  "(oracle/mtp_oracle_mt.c), %.1f s; 1 thread: %s" % (mp_, plan.nlocal, nthr, tmt, cpu["sample"])})
         # parity of the timed configuration, sampled: site energies of the sub-list
         ea = torch.zeros(plan.nall, dtype=torch.float64, device=dev)
         f.zero_()
@@ -312,9 +328,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mtp_wave_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": bytes_alg,
-                         "note": "fused kernel is fp64-VALU/LDS bound, not HBM bound (SURVEY.md 8d); "
-                                 "fp64 fraction below uses the REFERENCE algorithm's flop count",
-                         "lds": lds_block,
+                         "note": "fused kernel is LDS/fp64-issue bound, not HBM bound (SURVEY.md 8d): `pmc` holds the LDS and "
+                                 "VALU busy fractions from counters of this build; fp64_valu prices the REFERENCE "
+                                 "algorithm's flop count (SURVEY.md 8d F_alg), not the instructions executed",
+                         "pmc": pmc_block,
                          "fp64_valu": {"achieved": flops_ref / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
                                        "unit": "TFLOP/s",
                                        "frac": flops_ref / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,

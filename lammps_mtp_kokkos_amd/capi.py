@@ -73,6 +73,18 @@ def lib():
     return _lib
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources of the library: ties committed rocprofv3 counters to the build they came from."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    for n in sorted(os.listdir(src)):
+        if n.endswith((".hip", ".hpp", ".cpp")):
+            h.update(n.encode())
+            h.update(open(os.path.join(src, n), "rb").read())
+    return h.hexdigest()
+
+
 def use_private_torch_stream(device):
     """PyTorch's default stream is the legacy null stream (handle 0), and a null handle asks this library for the
     context's own NON-BLOCKING stream -- torch work and the library's kernels would then not be ordered with respect

@@ -505,6 +505,14 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
   }
 
   double tally = 0.0;   // lane 9: energy, lanes 3..8: virial components of this wave's atoms
+  // Global-only tallies need no per-atom reduction: the per-lane partial sums of the virial (and of the energy) run
+  // across the wavefront's atoms and cross the lanes once, after the atom loop.  Per-atom outputs (vatom: vflag & 4,
+  // eatom: eflag & 2) keep the per-atom reductions.
+  double vacc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, eacc = 0.0;
+  // (Only in the 2-per-SIMD build: at 168 VGPRs the seven extra accumulators spill and cost more than the per-atom
+  // reductions -- measured 0.514 against 0.500 ms.)
+  const bool v_per_atom = WPS == 3 ? kp->vflag != 0 : (kp->vflag & 4) != 0;
+  const bool e_per_atom = WPS == 3 ? true : (kp->eflag & 2) != 0;
 #ifdef MTP_STAMPS
   unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_prev = __builtin_amdgcn_s_memtime();
@@ -712,7 +720,8 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       for (int k = lane; k < kp->S; k += 64) e += bt.lin[k] * w.M[bt.map[k]];
     else
       for (int k = lane; k < kp->S; k += 64) e += kp->g_lin[k] * w.M[kp->g_map[k]];
-    e = wave_sum(e) + kp->species_coeffs[itype];
+    if (e_per_atom) e = wave_sum(e) + kp->species_coeffs[itype];
+    else eacc += e + (lane == 0 ? kp->species_coeffs[itype] : 0.0);
     // ---- 4b. adjoints (pair_mtp.cpp:217-233) ----------------------------------------------
     if (MTP_SCALARS_COND)
       for (int k = lane; k < kp->nseed; k += 64) w.D[bt.seed_idx[k]] = bt.seed_val[k];
@@ -862,7 +871,15 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     KP_FRESH();
     // ---- per-atom totals over the 64 lanes: lane v < 9 ends up with value v --------------------
     double tot;
-    if (kp->vflag) {
+    if (kp->vflag && !v_per_atom) {
+      vacc[0] += v0;
+      vacc[1] += v1;
+      vacc[2] += v2;
+      vacc[3] += v3;
+      vacc[4] += v4;
+      vacc[5] += v5;
+    }
+    if (v_per_atom) {
       double part16[16] = {fi0, fi1, fi2, v0, v1, v2, v3, v4, v5, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       Butterfly<16>::run(part16, lane);
       tot = part16[0];
@@ -882,12 +899,12 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     if (lane < 9) {
       if (lane < 3) {
         unsafeAtomicAdd(&kp->f[3 * (size_t) i + lane], tot);   // pair_mtp.cpp:248-250
-      } else if (kp->vflag) {
+      } else if (v_per_atom) {
         tally += tot;
         if ((kp->vflag & 4) && kp->vatom) kp->vatom[6 * (size_t) i + (lane - 3)] += tot;
       }
     }
-    if (lane == 9) {
+    if (e_per_atom && lane == 9) {
       if ((kp->eflag & 2) && kp->eatom) kp->eatom[i] = e;
       if (kp->eflag & 1) tally += e;
     }
@@ -899,6 +916,16 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
   if (lane == 0 && kp->stamps)
     for (int k = 0; k < 10; k++) atomicAdd(kp->stamps + k, st_acc[k]);
 #endif
+  if (kp->vflag && !v_per_atom) {   // the deferred virial: one transpose-reduce for all atoms of the wavefront
+    double part16[16] = {0.0, 0.0, 0.0, vacc[0], vacc[1], vacc[2], vacc[3], vacc[4], vacc[5], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    Butterfly<16>::run(part16, lane);
+    const double tot = pair_sum32(pair_sum16(part16[0]));
+    if (lane >= 3 && lane < 9) tally += tot;
+  }
+  if ((kp->eflag & 1) && !e_per_atom) {
+    const double et = wave_sum(eacc);
+    if (lane == 9) tally += et;
+  }
   if (lane >= 3 && lane <= 9 && tally != 0.0) {
     double *slot = kp->ev_slots + 8 * (size_t) ((blockIdx.x * wpb + wave) % MTP_EV_SLOTS);
     unsafeAtomicAdd(&slot[lane == 9 ? 0 : lane - 2], tally);

@@ -69,6 +69,12 @@ int mtp_oracle_compute(const mtp_oracle_model *m, int inum, const int *ilist, co
                        const int *neigh, const double *x, const int *type, int eflag, int vflag,
                        double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom);
 
+/* The same, threads over atoms (mtp_oracle_mt.c): nthreads slices of ilist, private force arrays, summed at the
+ * end.  bench.py's cpu_baseline leg (ii); nall = rows of x / f. */
+int mtp_oracle_compute_mt(const mtp_oracle_model *m, int nthreads, int nall, int inum, const int *ilist,
+                          const int *first, const int *neigh, const double *x, const int *type, int eflag,
+                          int vflag, double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom);
+
 /* pair_mtp_extrapolation.cpp:68-382.  Neighbourhood mode: grades[i] for i in ilist,
  * *max_grade = max.  Configuration mode: coeff_ders[C] = sum_i dE_i/dtheta (before any
  * cross-rank reduction), *max_grade = max|A^-1 c| / natoms when natoms > 0

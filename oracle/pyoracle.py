@@ -43,6 +43,7 @@ def lib():
         L.mtp_oracle_read_file.restype = C.c_int
         L.mtp_oracle_compute.restype = C.c_int
         L.mtp_oracle_compute_extrapolation.restype = C.c_int
+        L.mtp_oracle_compute_mt.restype = C.c_int
         L.mtp_oracle_grade.restype = C.c_double
         _LIB = L
     return _LIB
@@ -86,6 +87,28 @@ class Oracle:
         d = np.zeros(R)
         lib().mtp_oracle_radial_basis(C.byref(self.m), C.c_double(dist), _p(v, C.c_double), _p(d, C.c_double))
         return v, d
+
+    def compute_mt(self, nthreads, x, types, ilist, first, neigh, eflag=3, vflag=4):
+        """compute() with threads over atoms (private force arrays, summed at the end): the cpu_baseline leg that
+        uses every host core."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        types = np.ascontiguousarray(types, dtype=np.int32)
+        ilist = np.ascontiguousarray(ilist, dtype=np.int32)
+        first = np.ascontiguousarray(first, dtype=np.int32)
+        neigh = np.ascontiguousarray(neigh, dtype=np.int32)
+        nall = x.shape[0]
+        f = np.zeros((nall, 3))
+        eatom = np.zeros(nall)
+        vatom = np.zeros((nall, 6))
+        virial = np.zeros(6)
+        e = C.c_double(0.0)
+        rc = lib().mtp_oracle_compute_mt(C.byref(self.m), int(nthreads), nall, len(ilist), _p(ilist, C.c_int),
+                                         _p(first, C.c_int), _p(neigh, C.c_int), _p(x, C.c_double), _p(types, C.c_int),
+                                         eflag, vflag, _p(f, C.c_double), C.byref(e), _p(eatom, C.c_double),
+                                         _p(virial, C.c_double), _p(vatom, C.c_double))
+        if rc:
+            raise RuntimeError("oracle compute_mt rc=%d" % rc)
+        return dict(energy=e.value, eatom=eatom, f=f, virial=virial, vatom=vatom)
 
     def compute(self, x, types, ilist, first, neigh, eflag=3, vflag=4, extrapolation=False, natoms=0):
         """x [nall,3] f64, types [nall] i32 (1-based), CSR neighbour list over ilist.
