@@ -148,7 +148,7 @@ void mtp_context::plan()
     keep.m_doubles = m_keep;
     keep.off_nb = trows + std::max(3 * P * MTP_PITCH, d_doubles + m_keep);
     //   lean     [g rows | overlay]; the dg rows join the overlay behind the coefficient blocks and are written ahead
-    //            of the force phase from radial derivatives the tile build parked in registers (Mu <= 6): 12.4
+    //            of the force phase from radial derivatives the tile build parked in registers (Mu <= 4): 12.4
     //            instead of 15.7 KB per atom at level 16
     Layout lean = keep;
     lean.mode = 1;
@@ -158,7 +158,7 @@ void mtp_context::plan()
     lean.off_d = grows + m_keep;
     lean.off_coef = grows;
     lean.off_nb = grows + std::max(std::max(3 * P * MTP_PITCH, d_doubles + m_keep), p.coef_total + grows);
-    const bool lean_ok = p.radial_func_count <= 6;
+    const bool lean_ok = p.radial_func_count <= 4;
     //   rebuild  everything overlays everything (many moments): first table build = g rows and power rows only;
     //            moments and adjoints then take the front of the region; ahead of the force phase the g and dg rows
     //            are built again (coefficient blocks behind them, D[0, B) in front).  One more pass over the

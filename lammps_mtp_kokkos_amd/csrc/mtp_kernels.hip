@@ -105,12 +105,13 @@ template <int PITCH> struct WaveLds {
 
 // Phase 2: tables of one tile; columns [0, ntp) are written, ntp = nt rounded up to the
 // neighbour-group count with dummy neighbours sitting exactly on the cutoff (g = dg = 0).
-// with_dg: write the dg rows; park (lean layout, may be null): receives f'_mu(r) of this lane's neighbour for its radial
+// with_dg: write the dg rows; do_park (lean layout): park[] receives f'_mu(r) of this lane's neighbour for its radial
 // functions mu = h, h + 2, h + 4 (park[0..2]), from which dg_from_parked() writes the dg rows later.
-#define MTP_PARK 3   // radial functions per half-wavefront that can be parked: Mu <= 6
+#define MTP_PARK 2   // radial functions per half-wavefront that can be parked: Mu <= 4
 template <int PITCH>
 __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const WaveLds<PITCH> &w,
-                                           int t0, int cnt, int ntp, bool gather, bool powers, bool with_dg, double *park,
+                                           int t0, int cnt, int ntp, bool gather, bool powers, bool with_dg, bool do_park,
+                                           double (&park)[MTP_PARK],
                                            double xi0, double xi1, double xi2, int i, int itype, int lane)
 {
   if (gather) {
@@ -146,6 +147,18 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
     const double d = r - kp->rmax;
     const double ksi = (2.0 * r - (kp->rmin + kp->rmax)) * kp->inv_span;
     double *col = w.tab + n;
+    // radial functions of this half: mu = h, h + 2, ...; the first MTP_PARK of them with static indices, so that the
+    // parked derivatives stay in registers (a loop-carried index would put the array into scratch memory)
+    auto each_mu = [&](auto &&body) {
+      double d0 = 0.0, d1 = 0.0;
+      if (h < Mu) d0 = body(h);
+      if (h + 2 < Mu) d1 = body(h + 2);
+      for (int mu = h + 2 * MTP_PARK; mu < Mu; mu += 2) (void) body(mu);
+      if (do_park) {
+        park[0] = d0;
+        park[1] = d1;
+      }
+    };
     if (R == 8) {   // the MLIP default: basis in registers, coefficients in bursts of 16-byte reads
       double qv[8], ev[8];
       qv[0] = kp->scaling * (d * d);
@@ -157,8 +170,7 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
         qv[ri] = 2.0 * ksi * qv[ri - 1] - qv[ri - 2];
         ev[ri] = 2.0 * (mult * qv[ri - 1] + ksi * ev[ri - 1]) - ev[ri - 2];
       }
-      for (int mi = 0; 2 * mi + h < Mu; mi++) {
-        const int mu = 2 * mi + h;
+      each_mu([&](int mu) {
         const int4 *sl4 = reinterpret_cast<const int4 *>(bt.slot + mu * MTP_PSTRIDE);
         const int4 sa = sl4[0], sb = sl4[1], sc = sl4[2];
         const int sv[MTP_PSTRIDE] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w, sc.x, sc.y, sc.z, sc.w};
@@ -170,11 +182,6 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
         for (int ri = 1; ri < 8; ri++) {
           val = fma(cc[ri], qv[ri], val);
           der = fma(cc[ri], ev[ri], der);
-        }
-        if (park) {
-          if (mi == 0) park[0] = der;
-          else if (mi == 1) park[1] = der;
-          else park[2] = der;
         }
         double rp = 1.0;
 #pragma unroll
@@ -189,10 +196,10 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
             rp *= inv;
           }
         }
-      }
+        return der;
+      });
     } else {
-      for (int mi = 0; 2 * mi + h < Mu; mi++) {
-        const int mu = 2 * mi + h;
+      each_mu([&](int mu) {
         const int *sl = bt.slot + mu * MTP_PSTRIDE;
         const double *c = bt.radial + ((itype * kp->Sp + jt) * Mu + mu) * R;
         double q0 = kp->scaling * (d * d), q1 = kp->scaling * (ksi * d * d);
@@ -212,11 +219,6 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
           e0 = e1;
           e1 = e2;
         }
-        if (park) {
-          if (mi == 0) park[0] = der;
-          else if (mi == 1) park[1] = der;
-          else park[2] = der;
-        }
         double rp = 1.0;
         for (int nu = 0; nu < P; nu++) {
           const int sidx = sl[nu];
@@ -227,7 +229,8 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
           }
           rp *= inv;
         }
-      }
+        return der;
+      });
     }
     if (powers) {   // rows of one axis: [q] = u^q
       const double u0 = h == 0 ? w.nbx[n] : w.nbz[n];
@@ -257,7 +260,7 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
 // that stayed in LDS: d/dr (f_mu / r^nu) = f'_mu / r^nu - nu (f_mu / r^nu) / r, the expression of build_tile().
 template <int PITCH>
 __device__ __forceinline__ void dg_from_parked(KP kp, const BlockTables &bt, const WaveLds<PITCH> &w, int ntp,
-                                               const double *park, int lane)
+                                               const double (&park)[MTP_PARK], int lane)
 {
   const int n = lane & 31, h = lane >> 5, Mu = kp->Mu, P = kp->P;
   if (n < ntp) {
@@ -350,7 +353,10 @@ __device__ __forceinline__ void products_backward(const MtpRow8 *rows, const int
 template <int C> __device__ __forceinline__ double poly_eval(unsigned coef, const double *m)
 {
   double a0 = 0.0, a1 = 0.0;
-  constexpr int CH = 8;   // reads per burst
+#ifndef MTP_POLY_CH
+#define MTP_POLY_CH 8
+#endif
+  constexpr int CH = MTP_POLY_CH;   // reads per burst
 #pragma unroll
   for (int i0 = 0; i0 < C; i0 += CH) {
     double c[CH];
@@ -486,23 +492,28 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
   // the rows for this lane's neighbour column q.
   unsigned hg[NB][3], hx[NB][3], ty[NB][3], tz[NB][3];
   bool bval[NB];
+  // (2-per-SIMD build: formed once per kernel; 3-per-SIMD build: once per atom, so that the twelve registers are free
+  // outside the basic-moment pass)
+  auto block_addresses = [&](int kl_) {
 #pragma unroll
-  for (int t = 0; t < NB; t++) {
-    const int blk = kl + KL * t;
-    bval[t] = blk < kp->nfb;
-    const int *bd = bt.fwd + 8 * (bval[t] ? blk : 0);
-    const unsigned w0 = (unsigned) bd[0], w1 = (unsigned) bd[1], w2 = (unsigned) bd[2];
+    for (int t = 0; t < NB; t++) {
+      const int blk = kl_ + KL * t;
+      bval[t] = blk < kp->nfb;
+      const int *bd = bt.fwd + 8 * (bval[t] ? blk : 0);
+      const unsigned w0 = (unsigned) bd[0], w1 = (unsigned) bd[1], w2 = (unsigned) bd[2];
 #pragma unroll
-    for (int h = 0; h < 3; h++) {
-      hg[t][h] = w.addr(w.tab + (size_t) ((w0 >> (8 * h)) & 255u) * PITCH + q);
-      hx[t][h] = w.addr(w.tab + (size_t) (kp->pow_row + ((w1 >> (4 * h)) & 15u)) * PITCH + q);
-      ty[t][h] = w.addr(w.tab + (size_t) (kp->pow_row + P + ((w1 >> (12 + 4 * h)) & 15u)) * PITCH + q);
-      tz[t][h] = w.addr(w.tab + (size_t) (kp->pow_row + 2 * P + ((w2 >> (4 * h)) & 15u)) * PITCH + q);
-      // one finished address per register: stops the optimiser from re-splitting them into
-      // base + row offset (which costs a v_add per LDS read in the inner loops)
-      asm volatile("" : "+v"(hg[t][h]), "+v"(hx[t][h]), "+v"(ty[t][h]), "+v"(tz[t][h]));
+      for (int h = 0; h < 3; h++) {
+        hg[t][h] = w.addr(w.tab + (size_t) ((w0 >> (8 * h)) & 255u) * PITCH + q);
+        hx[t][h] = w.addr(w.tab + (size_t) (kp->pow_row + ((w1 >> (4 * h)) & 15u)) * PITCH + q);
+        ty[t][h] = w.addr(w.tab + (size_t) (kp->pow_row + P + ((w1 >> (12 + 4 * h)) & 15u)) * PITCH + q);
+        tz[t][h] = w.addr(w.tab + (size_t) (kp->pow_row + 2 * P + ((w2 >> (4 * h)) & 15u)) * PITCH + q);
+        // one finished address per register: stops the optimiser from re-splitting them into
+        // base + row offset (which costs a v_add per LDS read in the inner loops)
+        asm volatile("" : "+v"(hg[t][h]), "+v"(hx[t][h]), "+v"(ty[t][h]), "+v"(tz[t][h]));
+      }
     }
-  }
+  };
+  if constexpr (WPS != 3) block_addresses(kl);
 
   double tally = 0.0;   // lane 9: energy, lanes 3..8: virial components of this wave's atoms
   // Global-only tallies need no per-atom reduction: the per-lane partial sums of the virial (and of the energy) run
@@ -630,12 +641,17 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     for (int t = 0; t < NB; t++)
 #pragma unroll
       for (int e = 0; e < 9; e++) acc[t][e] = 0.0;
+    if constexpr (WPS == 3) {
+      int kl_o = kl;
+      asm volatile("" : "+v"(kl_o));   // opaque per atom: keeps the address arithmetic inside the loop
+      block_addresses(kl_o);
+    }
     const int ntiles = (cnt + NT - 1) / NT;
-    double park[MTP_PARK] = {0.0, 0.0, 0.0};   // lean layout: f'_mu(r) of this lane's neighbour (single-tile atoms)
+    double park[MTP_PARK] = {0.0, 0.0};   // lean layout: f'_mu(r) of this lane's neighbour (single-tile atoms)
     for (int tile = 0; tile < ntiles; tile++) {
       const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-      build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, tile > 0, true, kp->dg_mode == 0, kp->dg_mode == 1 ? park : nullptr, xi0,
-                        xi1, xi2, i, itype, lane);
+      build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, tile > 0, true, kp->dg_mode == 0, kp->dg_mode == 1, park, xi0, xi1, xi2, i,
+                        itype, lane);
       STAMP(2);   // tile tables
     KP_FRESH();
 #pragma unroll
@@ -781,7 +797,7 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       for (int tile = 0; tile < ntiles; tile++) {
         const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
         if (ntiles > 1 || kp->dg_mode == 2)
-          build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, ntiles > 1, false, true, nullptr, xi0, xi1, xi2, i, itype, lane);
+          build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, ntiles > 1, false, true, false, park, xi0, xi1, xi2, i, itype, lane);
         else if (kp->dg_mode == 1)
           dg_from_parked<PITCH>(kp, bt, w, ntp, park, lane);
         // columns past ntp hold stale (finite or not) data: their lanes are masked at the end
@@ -1204,12 +1220,16 @@ hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size
   if (wpb < 1 || wpb > (p.wps == 3 ? 12 : 8)) return hipErrorInvalidValue;
 #define MTP_CASE(kl, nb) \
   if (KL == kl && NB == nb) return launch_pitch<kl, nb>(p, grid, wpb, lds, st);
+#ifndef MTP_EXP_ONLY_KL32   // (compile-time experiments: only the level-16 lane grid)
   MTP_CASE(16, 1)
+#endif
   MTP_CASE(32, 1)
+#ifndef MTP_EXP_ONLY_KL32
   MTP_CASE(64, 1)
   MTP_CASE(64, 2)
   MTP_CASE(64, 3)
   MTP_CASE(64, 4)
+#endif
 #undef MTP_CASE
   return hipErrorInvalidValue;
 }
