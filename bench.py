@@ -138,17 +138,28 @@ def main():
     maxg_t = torch.zeros(1, dtype=torch.float64, device=dev) if grade else None
 
     # the halo: the library's RCCL exchange (production), or the torch twin (gloo rehearsals on one GPU)
-    halo, halo_info = None, None
+    halo, halo_info, halo_note = None, None, None
     if world > 1:
         if halo_kind == "native":
-            store = dist.distributed_c10d._get_default_store()     # rendezvous plumbing only: 128 bytes, once
-            if rank == 0:
-                store.set("mtp_halo_unique_id", capi.halo_unique_id())
-            uid = bytes(store.get("mtp_halo_unique_id"))
-            halo = capi.Halo(plan, devidx, uid)
-            halo_info = halo.comm_count()
-            assert halo_info["nranks"] == world and halo_info["rank"] == rank
-        else:
+            # every rank must end up on the same path: the outcome of the (collective) creation is agreed on below
+            ok = 1
+            try:
+                store = dist.distributed_c10d._get_default_store()     # rendezvous plumbing only: 128 bytes, once
+                if rank == 0:
+                    store.set("mtp_halo_unique_id", capi.halo_unique_id())
+                uid = bytes(store.get("mtp_halo_unique_id"))
+                halo = capi.Halo(plan, devidx, uid)
+                halo_info = halo.comm_count()
+                assert halo_info["nranks"] == world and halo_info["rank"] == rank
+            except Exception as exc:      # reported in the JSON line; the torch twin keeps the scaling run alive
+                ok, halo_note = 0, "library halo unavailable (%s: %s)" % (type(exc).__name__, exc)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                halo_kind, halo, halo_info = "torch", None, None
+                halo_note = halo_note or "library halo unavailable on another rank"
+                print("bench.py rank %d: %s -- falling back to the torch all-to-all halo" % (rank, halo_note), file=sys.stderr)
+        if halo_kind != "native":
             halo = HaloExchange(plan, dev)
 
     kw = dict(eflag=EFLAG, vflag=VFLAG, grade=grade, grades_t=grades_t, maxg_t=maxg_t, stream=stream)
@@ -193,7 +204,11 @@ def main():
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ev)
+        if halo_kind == "native":
+            halo.allreduce(ev, capi.REDUCE_SUM, stream)      # ncclAllReduce of {E, virial} on the library's communicator
+            torch.cuda.synchronize()
+        else:
+            dist.all_reduce(ev)
     dt = float(tmax.item())
     ctx.synchronize(stream)
     energy_per_atom = float(ev[0].item()) / args.steps / natoms
@@ -319,7 +334,8 @@ def main():
                        "parallelism": ("domain decomposition %s, %s%s" % (
                            "x".join(map(str, plan.grid)),
                            "library halo: grouped RCCL send/recv per direction (communicator of %d ranks, RCCL %d)"
-                           % (halo_info["nranks"], halo_info["rccl_version"]) if halo_info else "torch all-to-all halo (%s)" % backend,
+                           % (halo_info["nranks"], halo_info["rccl_version"]) if halo_info else "torch all-to-all halo (%s)%s" % (
+                               backend, "; " + halo_note if halo_note else ""),
                            ", rows interior|boundary|interior = %d|%d|%d overlap both exchanges" % (n_a, n_b, n_c) if use_rows else ""))
                        if world > 1 else "single GPU",
                        "atoms_rank0": plan.nlocal, "ghosts_rank0": plan.nghost, "list_entries_rank0": int(plan.first[-1]),

@@ -51,6 +51,15 @@ void PairMTP::load(const char *file, bool selection)
   int rc = mtp_potential_load(file, selection ? 1 : 0, &pot_, err, (int) sizeof(err));
   if (rc != MTP_OK) throw Error(rc, err);
   mtp_potential_get_info(pot_, &info);
+  logmesg(log_scaling(info.scaling));          // pair_mtp.cpp:383
+  logmesg(log_species(info.species_count));    // pair_mtp.cpp:389
+}
+
+void PairMTP::logmesg(const std::string &msg) const
+{
+  if (me_ != 0) return;   // the reference parses, hence logs, on rank 0 only (pair_mtp.cpp:343)
+  if (log_.write) log_.write(msg.c_str(), log_.ctx);
+  else std::fputs(msg.c_str(), stdout);
 }
 
 void PairMTP::settings(int narg, char **arg)
@@ -152,6 +161,7 @@ void PairMTPExtrapolation::settings(int narg, char **arg)
   }
   load(arg[0], true);
   configuration_mode = info.configuration_mode != 0;
+  logmesg(log_extrapolation_mode(mlip3_style, configuration_mode, select_threshold, break_threshold));   // :508-517
   energy_ders_wrt_coeffs.assign((size_t) info.coeff_count, 0.0);
   if (mlip3_style && red.me == 0) {
     preselected_file = std::fopen(arg[1], "w");
@@ -208,30 +218,19 @@ void PairMTPExtrapolation::evaluate_grades()
   }
 }
 
-// MLIP-3 .cfg record of the current configuration (:401-479).  One rank writes; with several ranks
-// the caller gathers the per-rank atom lines (the reference serialises them with MPI_Send/Recv).
+// MLIP-3 .cfg record of the current configuration (:401-479): every rank formats its atom lines, rank 0 writes the
+// header, its own lines, then the other ranks' in rank order (mtp_cfg_writer.hpp; the exchanges go through `red`).
 void PairMTPExtrapolation::write_config()
 {
-  if (red.me != 0 || !preselected_file) return;
-  std::FILE *fp = preselected_file;
-  std::fprintf(fp, "BEGIN_CFG\nSize\n%ld\nSupercell\n", atom.natoms);
-  std::fprintf(fp, "%.6f %.6f %.6f\n", box.xprd, 0.0, 0.0);
-  std::fprintf(fp, "%.6f %.6f %.6f\n", box.xy, box.yprd, 0.0);
-  std::fprintf(fp, "%.6f %.6f %.6f\n", box.xz, box.yz, box.zprd);
-  if (!configuration_mode)
-    std::fprintf(fp, "AtomData:  id type       cartes_x      cartes_y      cartes_z       nbh_grades\n");
-  else
-    std::fprintf(fp, "AtomData:  id type       cartes_x      cartes_y      cartes_z\n");
-  for (int i = 0; i < atom.nlocal; i++) {   // the reference indexes atoms 0..inum-1 here (:418-422)
-    const double *xi = atom.x + 3 * (size_t) i;
-    if (!configuration_mode)
-      std::fprintf(fp, "%d\t%d\t%.6f\t%.6f\t%.6f\t%.5f\n", i + 1, atom.type[i] - 1, xi[0], xi[1], xi[2],
-                   nbh_extrapolation_grades[(size_t) i]);
-    else
-      std::fprintf(fp, "%d\t%d\t%.6f\t%.6f\t%.6f\n", i + 1, atom.type[i] - 1, xi[0], xi[1], xi[2]);
-  }
-  std::fprintf(fp, "Feature   MV_grade\t%.6f\nEND_CFG\n\n", max_grade);
-  std::fflush(fp);
+  CfgComm cc;
+  cc.me = red.me;
+  cc.nprocs = red.nprocs;
+  cc.ctx = red.ctx;
+  cc.scan_sum = red.scan_sum;
+  cc.send_to_root = red.send_to_root;
+  cc.recv_on_root = red.recv_on_root;
+  cfg_write_record(preselected_file, cc, atom.natoms, box, configuration_mode, atom.nlocal, atom.type, atom.x,
+                   configuration_mode ? nullptr : nbh_extrapolation_grades.data(), max_grade);
 }
 
 void *PairMTPExtrapolation::extract(const char *str, int &dim)

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/mtp_mi355x.h"
+#include "mtp_cfg_writer.hpp"
 
 namespace mtp_mi355x {
 
@@ -35,15 +36,24 @@ struct NeighListView {
   const int *numneigh = nullptr;
   const int *const *firstneigh = nullptr;
 };
-struct BoxView {   // domain->xprd ... for the .cfg writer (pair_mtp_extrapolation.cpp:449-451)
-  double xprd = 0, yprd = 0, zprd = 0, xy = 0, xz = 0, yz = 0;
-};
+using BoxView = CfgBox;   // domain->xprd ... for the .cfg writer (pair_mtp_extrapolation.cpp:449-451)
 // cross-rank reductions (LAMMPS: MPI_Allreduce on `world`); identity when unset (one rank)
 struct Reductions {
   void (*sum)(double *buf, int n, void *ctx) = nullptr;
   void (*max)(double *buf, int n, void *ctx) = nullptr;
   void *ctx = nullptr;
   int me = 0, nprocs = 1;
+  // the .cfg writer's exchanges (mtp_cfg_writer.hpp: MPI_Scan, MPI_Send / MPI_Recv to rank 0); me / nprocs / ctx are
+  // taken from above
+  int (*scan_sum)(int value, void *ctx) = nullptr;
+  void (*send_to_root)(const char *buf, size_t n, void *ctx) = nullptr;
+  void (*recv_on_root)(int src, std::string &out, void *ctx) = nullptr;
+};
+// utils::logmesg stand-in: the reference reports the scaling, the species count and the extrapolation mode from rank 0
+// (pair_mtp.cpp:383, 389; pair_mtp_extrapolation.cpp:508-517).  Default: stdout.
+struct LogSink {
+  void (*write)(const char *msg, void *ctx) = nullptr;
+  void *ctx = nullptr;
 };
 
 // pair_style mtp <file>            (pair_mtp.cpp:285-297)
@@ -66,6 +76,8 @@ class PairMTP {
   // bindings in place of the LAMMPS pointers
   void bind(const AtomView &a) { atom = a; }
   void set_neighbor_list(const NeighListView &l);   // call after every re-neighbouring
+  void set_log(const LogSink &l) { log_ = l; }
+  void set_rank(int me) { me_ = me; }               // comm->me: only rank 0 logs
 
   // what LAMMPS reads back (pair.h)
   double eng_vdwl = 0.0, virial[6] = {0, 0, 0, 0, 0, 0};
@@ -77,6 +89,9 @@ class PairMTP {
   void ev_setup(int eflag, int vflag);
   void require(int rc, const char *what);
   void load(const char *file, bool selection);
+  void logmesg(const std::string &msg) const;
+  LogSink log_;
+  int me_ = 0;
   Style style_;
   int device_;
   mtp_potential *pot_ = nullptr;
@@ -96,7 +111,11 @@ class PairMTPExtrapolation : public PairMTP {
   void compute(int eflag, int vflag) override;
   void *extract(const char *str, int &dim);           // "extrapolation_flag" (:624-631)
   void *extract_peratom(const char *str, int &ncol);  // "extrapolation" (:641-652)
-  void set_reductions(const Reductions &r) { red = r; }
+  void set_reductions(const Reductions &r)
+  {
+    red = r;
+    me_ = r.me;
+  }
   void set_box(const BoxView &b) { box = b; }
 
   int nextra = 1;

@@ -3,9 +3,11 @@
 // text file written by tests/test_pair_host.py.
 //
 //   test_pair_host args                                   argument-grammar checks (no GPU needed)
+//   test_pair_host cfg <system> <outdir> <0|1>            .cfg records of 1-, 2- and 3-rank jobs (no GPU needed)
 //   test_pair_host run    <style> <system> <out> <pair_style args...>
 //   test_pair_host runext <style> <system> <out> <pair_style args...>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -121,10 +123,79 @@ static int check_args(const char *l8, const char *nbh)
   return bad;
 }
 
+// ---- the .cfg writer over several ranks (no GPU): the ranks of one "job" run one after the other in this process and
+// talk through an in-memory mailbox that stands for MPI_Scan / MPI_Send / MPI_Recv; the file of a 1-, 2- and 3-rank
+// job over the same atoms must be the same, byte for byte (pair_mtp_extrapolation.cpp:401-479)
+struct Mailbox {
+  std::vector<int> counts;              // inum of every rank
+  std::vector<std::string> sent;        // what rank r handed to rank 0
+  int me = 0;
+};
+static int mb_scan(int value, void *ctx)
+{
+  Mailbox *m = (Mailbox *) ctx;
+  int s = 0;
+  for (int r = 0; r <= m->me; r++) s += m->counts[r];
+  return m->counts[m->me] == value ? s : -1000000;
+}
+static void mb_send(const char *buf, size_t n, void *ctx)
+{
+  Mailbox *m = (Mailbox *) ctx;
+  m->sent[m->me].assign(buf, n);
+}
+static void mb_recv(int src, std::string &out, void *ctx) { out = ((Mailbox *) ctx)->sent[src]; }
+
+static int write_cfg_jobs(const char *sysfile, const char *outdir, int mode_cfg)
+{
+  System s;
+  s.read(sysfile);
+  std::vector<double> grades(s.nlocal);
+  for (int i = 0; i < s.nlocal; i++) grades[i] = 0.37 * i + 1.0 / (i + 3.0);
+  CfgBox box;
+  box.xprd = s.box[0];
+  box.yprd = s.box[1];
+  box.zprd = s.box[2];
+  box.xy = 0.25;
+  box.xz = -0.5;
+  box.yz = 0.125;
+  for (int nprocs = 1; nprocs <= 3; nprocs++) {
+    Mailbox mb;
+    mb.counts.resize(nprocs);
+    mb.sent.resize(nprocs);
+    std::vector<int> start(nprocs + 1, 0);
+    for (int r = 0; r < nprocs; r++) {   // uneven shards, one of them possibly empty
+      start[r + 1] = r + 1 == nprocs ? s.nlocal : (nprocs == 3 && r == 1 ? start[r] : (r + 1) * s.nlocal / (nprocs + 1));
+      mb.counts[r] = start[r + 1] - start[r];
+    }
+    const std::string path = std::string(outdir) + "/cfg_" + std::to_string(nprocs) + ".cfg";
+    std::FILE *fp = std::fopen(path.c_str(), "w");
+    if (!fp) return 1;
+    for (int pass = 0; pass < 2; pass++)     // senders first, then the root: a valid schedule of the message passing
+      for (int r = nprocs - 1; r >= 0; r--) {
+        if ((pass == 0) == (r == 0)) continue;
+        mb.me = r;
+        CfgComm cc;
+        cc.me = r;
+        cc.nprocs = nprocs;
+        cc.ctx = &mb;
+        cc.scan_sum = mb_scan;
+        cc.send_to_root = mb_send;
+        cc.recv_on_root = mb_recv;
+        cfg_write_record(r == 0 ? fp : nullptr, cc, s.nlocal, box, mode_cfg != 0, mb.counts[r], s.type.data() + start[r],
+                         s.x.data() + 3 * (size_t) start[r], grades.data() + start[r], 3.14159265);
+      }
+    std::fclose(fp);
+  }
+  std::printf("%s%s%s", log_scaling(1.0).c_str(), log_species(2).c_str(),
+              (log_extrapolation_mode(true, false, 2.0, 10.5) + log_extrapolation_mode(false, true, 0, 0)).c_str());
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
   try {
     if (argc >= 4 && !std::strcmp(argv[1], "args")) return check_args(argv[2], argv[3]);
+    if (argc >= 5 && !std::strcmp(argv[1], "cfg")) return write_cfg_jobs(argv[2], argv[3], std::atoi(argv[4]));
     if (argc < 6) {
       std::fprintf(stderr, "usage: see the header of this file\n");
       return 2;

@@ -36,6 +36,41 @@ def test_argument_grammar_and_errors():
     assert out.returncode == 0 and "ARGS OK" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("cfg_mode", [0, 1])
+def test_cfg_writer_across_ranks_is_byte_identical_to_one_rank(tmp_path, cfg_mode):
+    """pair_mtp_extrapolation.cpp:401-479: offsets by MPI_Scan, atom lines gathered on rank 0 in rank order.  The file
+    a 2- or 3-rank job writes (uneven shards, one empty) equals the 1-rank file, which equals the format spelled out
+    here line by line."""
+    _build()
+    pos, box = mtpgen.bcc_lattice(2, 2, 3)
+    rng = np.random.default_rng(8)
+    types = rng.integers(1, 3, len(pos)).astype(np.int32)
+    s = periodic_system(pos, box, types, 4.0)
+    sysf = str(tmp_path / "sys.txt")
+    _write_system(sysf, s)
+    r = subprocess.run([EXE, "cfg", sysf, str(tmp_path), str(cfg_mode)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    one = open(tmp_path / "cfg_1.cfg", "rb").read()
+    assert one == open(tmp_path / "cfg_2.cfg", "rb").read()
+    assert one == open(tmp_path / "cfg_3.cfg", "rb").read()
+    n = s.nlocal
+    grades = [0.37 * i + 1.0 / (i + 3.0) for i in range(n)]
+    want = ["BEGIN_CFG", "Size", "%d" % n, "Supercell", "%.6f %.6f %.6f" % (s.box[0], 0, 0),
+            "%.6f %.6f %.6f" % (0.25, s.box[1], 0), "%.6f %.6f %.6f" % (-0.5, 0.125, s.box[2])]
+    if cfg_mode:
+        want.append("AtomData:  id type       cartes_x      cartes_y      cartes_z")
+        want += ["%d\t%d\t%.6f\t%.6f\t%.6f" % (i + 1, s.types[i] - 1, *s.x[i]) for i in range(n)]
+    else:
+        want.append("AtomData:  id type       cartes_x      cartes_y      cartes_z       nbh_grades")
+        want += ["%d\t%d\t%.6f\t%.6f\t%.6f\t%.5f" % (i + 1, s.types[i] - 1, *s.x[i], grades[i]) for i in range(n)]
+    want += ["Feature   MV_grade\t%.6f" % 3.14159265, "END_CFG", "", ""]
+    assert one.decode() == "\n".join(want)
+    # the three utils::logmesg lines of the reference (pair_mtp.cpp:383, 389; pair_mtp_extrapolation.cpp:508-517)
+    assert r.stdout == ("The scaling is : 1.00e+00.\nThere are 2 species.\n"
+                        "Extrapolation Scheme: Neighborhood mode, with a selection threshold of 2 and break threshold of 10.5.\n"
+                        "Extrapolation Mode: Configuration mode.\n")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("style,extra", [("mtp", []), ("mtp/kk", ["chunksize", "32768"]),
                                          ("mtp/small/kk", ["chunksize", "4096"])])
