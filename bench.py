@@ -60,6 +60,7 @@ def main():
                     help="w16: BASELINE configs[1] (default); small2k: configs[2]; wre20: level-20 W-Re shard of "
                          "configs[3]; grades: configs[4] (MaxVol neighbourhood grades every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-whole-step", action="store_true", help="skip the device-resident MD loop (whole-step time)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -316,6 +317,37 @@ def main():
         list_build_ms = (time.perf_counter() - c0) / 5 * 1e3
         del cnb
 
+    # ---- whole MD step ("force-only and whole-step"), N = 1: velocity-Verlet with everything in HBM --
+    # kick + drift, ghost refresh, force call (same flags as above), ghost-force fold, kick; every 10th step the
+    # ghost images and the neighbour list are rebuilt on the device (lammps_mtp_kokkos_amd/md.py)
+    whole = None
+    if rank == 0 and world == 1 and not grade and not args.no_whole_step:
+        from lammps_mtp_kokkos_amd.md import DeviceNVE, MVV2E
+        ctx_md = capi.Context(pot, devidx)
+        ctx_md.set_variant(dict(auto=0, large=1, small=2)[args.variant])
+        md = DeviceNVE(ctx_md, pos, box, rc=pot.info.max_cutoff, types=gtypes, mass=183.84, list_cutoff=list_cutoff,
+                       device=dev, every=10, check_every=0, vflag=VFLAG)
+        rng = np.random.default_rng(300)
+        vel = rng.normal(size=pos.shape) * np.sqrt(8.617343e-5 * 30.0 / (183.84 * MVV2E))   # 30 K
+        md.v.copy_(torch.from_numpy(vel - vel.mean(0)).to(dev))
+        dt_ps, nmd = 2.5e-4, 60      # the synthetic potential is stiff: 0.25 fs (the time does not depend on dt)
+        for _ in range(10):
+            md.step(dt_ps)
+        torch.cuda.synchronize()
+        e0, b0 = md.total_energy(), md.builds
+        c0 = time.perf_counter()
+        for _ in range(nmd):
+            md.step(dt_ps)
+        torch.cuda.synchronize()
+        wdt = time.perf_counter() - c0
+        whole = {"ms_per_step": wdt / nmd * 1e3, "atom_steps_per_s": natoms * nmd / wdt, "steps": nmd,
+                 "reneighbor_every": 10, "rebuilds_in_timed_steps": md.builds - b0, "dt_fs": dt_ps * 1e3,
+                 "ghosts": md.nall - md.n, "list_entries": int(md.entries),
+                 "energy_drift_eV_per_atom": (md.total_energy() - e0) / natoms,
+                 "what": "velocity-Verlet, all arrays resident in HBM: kick+drift, ghost refresh, force call (eflag=1 "
+                         "vflag=%d), ghost-force fold, kick; ghost images + full list rebuilt on the device every 10 steps" % VFLAG}
+        del md, ctx_md
+
     if rank == 0:
         value = natoms * args.steps / dt
         info = ctx.launch_info()
@@ -353,6 +385,7 @@ def main():
                                        "frac": flops_ref / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                        "reference_flops_per_launch": flops_ref}},
             "cpu_baseline": cpu,
+            "whole_step": whole,
             "energy_per_atom_eV": energy_per_atom,
         }
         print(json.dumps(line))

@@ -216,6 +216,35 @@ int mtp_halo_reverse(mtp_halo *halo, void *stream, double *d_f);
  * pair_mtp_extrapolation.cpp:369), the neighbourhood-mode maximum grade (MAX, :379) */
 int mtp_halo_allreduce(mtp_halo *halo, void *stream, double *d_buf, int count, int op);
 
+/* ---- standalone MD support: LAMMPS-core work either side of Pair::compute, on the device ------
+ *
+ * For drivers that keep the whole step in HBM (bench.py's whole-step number, lammps_mtp_kokkos_amd/md.py): the
+ * periodic ghost images of ONE GPU's own atoms (Comm::borders / forward_comm / reverse_comm of a single rank; the
+ * pair style needs them because it writes forces onto ghosts, pair_mtp.cpp:252-254, 315) and the two halves of a
+ * velocity-Verlet step (fix nve).  Orthogonal box [0, box), every edge >= rghost.
+ */
+typedef struct mtp_ghosts mtp_ghosts;
+int mtp_ghosts_create(int device_id, mtp_ghosts **out);
+void mtp_ghosts_destroy(mtp_ghosts *g);
+const char *mtp_ghosts_last_error(const mtp_ghosts *g);
+/* Re-neighbouring: wraps d_x[0, nlocal) into the box, finds every periodic image within rghost of the box (atom
+ * order, then lexicographic shift order: deterministic) and writes their positions behind the owned atoms.
+ * *nall_out = nlocal + ghosts; MTP_ERR_LIMIT (nothing written beyond the wrap) when that exceeds `capacity` rows.
+ * Synchronises the stream once (the ghost count sizes the caller's arrays and the neighbour list). */
+int mtp_ghosts_build(mtp_ghosts *g, void *stream, double *d_x /*[capacity][3]*/, int nlocal, int capacity,
+                     const double box[3], double rghost, int *nall_out);
+int mtp_ghosts_forward(mtp_ghosts *g, void *stream, double *d_x);   /* ghost rows <- owner + shift            */
+int mtp_ghosts_reverse(mtp_ghosts *g, void *stream, double *d_f);   /* owner rows += ghost rows (fp64 atomics) */
+int mtp_ghosts_types(mtp_ghosts *g, void *stream, int *d_type);     /* ghost types <- owner types              */
+/* fix nve (metal units: dtf = 0.5 dt ftm2v): v += dtf f / m; x += dt v   and   v += dtf f / m; masses per type */
+int mtp_nve_initial(void *stream, int nlocal, double *d_x, double *d_v, const double *d_f, const int *d_type,
+                    const double *d_inv_mass, double dtf, double dt);
+int mtp_nve_final(void *stream, int nlocal, double *d_v, const double *d_f, const int *d_type,
+                  const double *d_inv_mass, double dtf);
+/* d_out2[0] = max_i |x_i - x_ref_i|^2 (the half-skin re-neighbouring test), d_out2[1] = sum_i m_i v_i^2 */
+int mtp_nve_monitor(void *stream, int nlocal, const double *d_x, const double *d_x_ref, const double *d_v,
+                    const int *d_type, const double *d_mass, double *d_out2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,8 @@ EXPORTS = [
     "mtp_halo_get_unique_id", "mtp_halo_create", "mtp_halo_destroy", "mtp_halo_last_error", "mtp_halo_comm_count",
     "mtp_halo_forward_begin", "mtp_halo_forward_end", "mtp_halo_forward", "mtp_halo_reverse_begin",
     "mtp_halo_reverse_end", "mtp_halo_reverse", "mtp_halo_allreduce",
+    "mtp_ghosts_create", "mtp_ghosts_destroy", "mtp_ghosts_last_error", "mtp_ghosts_build", "mtp_ghosts_forward",
+    "mtp_ghosts_reverse", "mtp_ghosts_types", "mtp_nve_initial", "mtp_nve_final", "mtp_nve_monitor",
 ]
 HALO_ID_BYTES = 128
 REDUCE_SUM, REDUCE_MAX = 0, 1
@@ -66,6 +68,8 @@ def lib():
             getattr(L, n).restype = C.c_int
         L.mtp_last_error.restype = C.c_char_p
         L.mtp_halo_last_error.restype = C.c_char_p
+        L.mtp_ghosts_last_error.restype = C.c_char_p
+        L.mtp_ghosts_destroy.restype = None
         L.mtp_potential_free.restype = None
         L.mtp_context_destroy.restype = None
         L.mtp_halo_destroy.restype = None
@@ -353,3 +357,64 @@ class Halo:
 
     def allreduce(self, buf_t, op=REDUCE_SUM, stream=None):
         self._check(lib().mtp_halo_allreduce(self.h, self._st(stream), _ptr(buf_t), int(buf_t.numel()), int(op)))
+
+
+class Ghosts:
+    """Periodic ghost images of one GPU's own atoms, kept on the device (mtp_ghosts_*)."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        rc = lib().mtp_ghosts_create(int(device), C.byref(self.h))
+        if rc:
+            raise MtpError(rc, "mtp_ghosts_create")
+        self.nall = 0
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mtp_ghosts_destroy(self.h)
+            self.h = None
+
+    def _check(self, rc):
+        if rc:
+            raise MtpError(rc, lib().mtp_ghosts_last_error(self.h).decode())
+
+    def build(self, x_t, nlocal, box, rghost, stream=None):
+        """Wraps x_t[:nlocal] and writes the ghost positions behind them; returns nall.  x_t must have room:
+        raises MtpError(LIMIT) otherwise, with self.nall set to the size needed."""
+        b3 = (C.c_double * 3)(*[float(v) for v in box])
+        nall = C.c_int(0)
+        rc = lib().mtp_ghosts_build(self.h, C.c_void_p(stream) if stream else None, _ptr(x_t), int(nlocal),
+                                    int(x_t.shape[0]), b3, C.c_double(rghost), C.byref(nall))
+        self.nall = nall.value
+        self._check(rc)
+        return nall.value
+
+    def forward(self, x_t, stream=None):
+        self._check(lib().mtp_ghosts_forward(self.h, C.c_void_p(stream) if stream else None, _ptr(x_t)))
+
+    def reverse(self, f_t, stream=None):
+        self._check(lib().mtp_ghosts_reverse(self.h, C.c_void_p(stream) if stream else None, _ptr(f_t)))
+
+    def types(self, type_t, stream=None):
+        self._check(lib().mtp_ghosts_types(self.h, C.c_void_p(stream) if stream else None, _ptr(type_t)))
+
+
+def nve_initial(nlocal, x_t, v_t, f_t, type_t, inv_mass_t, dtf, dt, stream=None):
+    rc = lib().mtp_nve_initial(C.c_void_p(stream) if stream else None, int(nlocal), _ptr(x_t), _ptr(v_t), _ptr(f_t),
+                               _ptr(type_t), _ptr(inv_mass_t), C.c_double(dtf), C.c_double(dt))
+    if rc:
+        raise MtpError(rc, "mtp_nve_initial")
+
+
+def nve_final(nlocal, v_t, f_t, type_t, inv_mass_t, dtf, stream=None):
+    rc = lib().mtp_nve_final(C.c_void_p(stream) if stream else None, int(nlocal), _ptr(v_t), _ptr(f_t), _ptr(type_t),
+                             _ptr(inv_mass_t), C.c_double(dtf))
+    if rc:
+        raise MtpError(rc, "mtp_nve_final")
+
+
+def nve_monitor(nlocal, x_t, x_ref_t, v_t, type_t, mass_t, out2_t, stream=None):
+    rc = lib().mtp_nve_monitor(C.c_void_p(stream) if stream else None, int(nlocal), _ptr(x_t), _ptr(x_ref_t), _ptr(v_t),
+                               _ptr(type_t), _ptr(mass_t), _ptr(out2_t))
+    if rc:
+        raise MtpError(rc, "mtp_nve_monitor")

@@ -1,107 +1,128 @@
 """Device-resident velocity-Verlet (NVE) driver around the MTP force call -- the standalone counterpart of what
-LAMMPS' Verlet / Comm / Neighbor classes do around `Pair::compute`: positions,
-velocities, forces, ghosts and the neighbour list all stay in HBM between steps.
+LAMMPS' Verlet / Comm / Neighbor classes do around `Pair::compute`.  Positions,
+velocities, forces, ghost maps and the neighbour list stay in HBM between steps; every piece of the step is one of
+the library's HIP kernels (include/mtp_mi355x.h, "standalone MD support"):
 
-  per step      ghosts <- owners + periodic shift (index_select), force call (mtp_compute_device), ghost forces
-                folded onto their owners (index_add_: newton_pair on, /root/reference/LAMMPS/ML-MTP/pair_mtp.cpp:252-254,
-                315), two half kicks and a drift (metal units)
-  every `every` steps (or when an atom moved more than half the skin, checked on the device)
-                ghost set rebuilt from the wrapped positions, full list rebuilt on the GPU
-                (mtp_build_neighbors_device)
+  per step      mtp_nve_initial (kick + drift) -> mtp_ghosts_forward (ghosts follow their owners) -> force call
+                (mtp_compute_device) -> mtp_ghosts_reverse (ghost forces onto owners: newton_pair on,
+                /root/reference/LAMMPS/ML-MTP/pair_mtp.cpp:252-254, 315) -> mtp_nve_final (kick)
+  every `every` steps (or when an atom moved more than half the skin: mtp_nve_monitor, one 16-byte read-back)
+                mtp_ghosts_build (wrap + periodic images, on the device) and mtp_build_neighbors_device
 
-torch is plumbing here (index maps, axpy); the force call and the list build are the library's HIP kernels.
+torch only allocates the arrays and provides the stream; the host sees the ghost count and the list size at a
+re-neighbouring (they size arrays) and nothing else.
 """
 from __future__ import annotations
 
 import numpy as np
 
-from .driver import make_ghosts
+from . import capi
 
 MVV2E = 1.0364269e-4          # (g/mol)(A/ps)^2 -> eV     (LAMMPS metal units)
 FTM2V = 1.0 / MVV2E           # eV/A / (g/mol) -> A/ps^2
 
 
 class DeviceNVE:
-    def __init__(self, ctx, pos, box, rc, types=None, mass=183.84, list_cutoff=7.0, device=None, every=10):
+    def __init__(self, ctx, pos, box, rc, types=None, mass=183.84, list_cutoff=7.0, device=None, every=10,
+                 check_every=4, vflag=0):
         import torch
         self.torch = torch
         self.ctx = ctx
         self.dev = device or torch.device("cuda:0")
         # torch's default stream is the null stream, which the library maps to its own non-blocking stream: use one
-        # real stream for the index maps, the axpys and the library's kernels so that they are ordered
+        # real stream for the allocations' fills and the library's kernels so that they are ordered
         if torch.cuda.current_stream(self.dev).cuda_stream == 0:
-            from .capi import use_private_torch_stream
-            use_private_torch_stream(self.dev)
+            capi.use_private_torch_stream(self.dev)
+        self.st = torch.cuda.current_stream(self.dev).cuda_stream
         self.box_np = np.asarray(box, dtype=np.float64)
-        self.box = torch.from_numpy(self.box_np).to(self.dev)
         self.n = len(pos)
-        self.types_np = np.ones(self.n, dtype=np.int32) if types is None else np.asarray(types, dtype=np.int32)
-        self.mass = float(mass)
+        types_np = np.ones(self.n, dtype=np.int32) if types is None else np.asarray(types, dtype=np.int32)
+        masses = np.atleast_1d(np.asarray(mass, dtype=np.float64))
+        if len(masses) < int(types_np.max()):
+            masses = np.full(int(types_np.max()), float(masses[0]))
+        self.mass_t = torch.from_numpy(masses).to(self.dev)
+        self.inv_mass_t = torch.from_numpy(1.0 / masses).to(self.dev)
         self.cut = float(list_cutoff)
         self.rc = float(rc)                # potential cutoff: skin = list_cutoff - rc
         self.every = int(every)
-        self.x = torch.from_numpy(np.ascontiguousarray(pos, dtype=np.float64)).to(self.dev)   # owned, unwrapped
-        self.v = torch.zeros_like(self.x)
+        self.check_every = int(check_every)
+        self.vflag = int(vflag)          # 1: the global virial is tallied too (as in the headline benchmark)
+        self.ghosts = capi.Ghosts(self.dev.index or 0)
+        self.cap = 0
+        self._alloc(int(self.n * 1.6) + 1024, pos, types_np)
+        self.v = torch.zeros((self.n, 3), dtype=torch.float64, device=self.dev)
         self.ev = torch.zeros(8, dtype=torch.float64, device=self.dev)
+        self.mon = torch.zeros(2, dtype=torch.float64, device=self.dev)
+        self.x_ref = torch.empty((self.n, 3), dtype=torch.float64, device=self.dev)
         self.steps_since_build = 0
         self.builds = 0
-        self.energy = 0.0
         self._reneighbor()
         self._forces()
 
-    # ---- ghosts + list (re-neighbouring) ------------------------------------------------------------
-    def _reneighbor(self):
+    @property
+    def x(self):
+        """owned atoms (wrapped into the box at the last re-neighbouring)"""
+        return self.xall[: self.n]
+
+    @property
+    def f(self):
+        return self.fall[: self.n]
+
+    def _alloc(self, cap, pos=None, types_np=None):
         torch = self.torch
-        pos = self.x.cpu().numpy()
-        wrapped = pos - np.floor(pos / self.box_np) * self.box_np
-        xall, owner = make_ghosts(wrapped, self.box_np, self.cut)
-        self.nall = len(xall)
-        self.owner = torch.from_numpy(owner.astype(np.int64)).to(self.dev)
-        # ghost k sits at x[owner] + shift; owned atoms get their wrap shift, so xall = x[owner] + shift exactly
-        shift = xall - pos[owner]
-        self.shift = torch.from_numpy(shift).to(self.dev)
-        self.types_all = torch.from_numpy(self.types_np[owner]).to(self.dev)
-        self.xall = torch.empty((self.nall, 3), dtype=torch.float64, device=self.dev)
-        self.fall = torch.zeros((self.nall, 3), dtype=torch.float64, device=self.dev)
-        self._update_ghosts()
-        lo = -self.cut - 1.0
+        xall = torch.zeros((cap, 3), dtype=torch.float64, device=self.dev)
+        tall = torch.ones(cap, dtype=torch.int32, device=self.dev)
+        if pos is not None:
+            xall[: self.n] = torch.from_numpy(np.ascontiguousarray(pos, dtype=np.float64)).to(self.dev)
+            tall[: self.n] = torch.from_numpy(types_np).to(self.dev)
+        else:
+            xall[: self.n] = self.xall[: self.n]
+            tall[: self.n] = self.types_all[: self.n]
+        self.xall, self.types_all = xall, tall
+        self.fall = torch.zeros((cap, 3), dtype=torch.float64, device=self.dev)
+        self.cap = cap
+
+    # ---- ghosts + list (re-neighbouring), all on the device ----------------------------------------------------
+    def _reneighbor(self):
+        try:
+            self.nall = self.ghosts.build(self.xall, self.n, self.box_np, self.cut, stream=self.st)
+        except capi.MtpError as e:
+            if e.code != -24 or self.ghosts.nall <= self.cap:
+                raise
+            self._alloc(int(self.ghosts.nall * 1.2) + 1024)
+            self.nall = self.ghosts.build(self.xall, self.n, self.box_np, self.cut, stream=self.st)
+        self.ghosts.types(self.types_all, stream=self.st)
+        lo = [-self.cut - 1.0] * 3
         hi = self.box_np + self.cut + 1.0
-        self.entries, self.max_row = self.ctx.build_neighbors_device(self.xall, self.n, self.nall, self.cut,
-                                                                     [lo, lo, lo], hi,
-                                                                     stream=torch.cuda.current_stream().cuda_stream)
-        self.x_at_build = self.x.clone()
+        self.entries, self.max_row = self.ctx.build_neighbors_device(self.xall, self.n, self.nall, self.cut, lo, hi,
+                                                                     stream=self.st)
+        self.x_ref.copy_(self.xall[: self.n])
         self.steps_since_build = 0
         self.builds += 1
 
-    def _update_ghosts(self):
-        self.torch.index_select(self.x, 0, self.owner, out=self.xall)
-        self.xall += self.shift
-
     def _forces(self):
-        torch = self.torch
-        self._update_ghosts()
-        self.fall.zero_()
+        self.ghosts.forward(self.xall, stream=self.st)
+        self.fall[: self.nall].zero_()
         self.ev.zero_()
-        self.ctx.compute_device(self.xall, self.types_all, self.fall, eflag=1, vflag=0, ev_t=self.ev,
-                                stream=torch.cuda.current_stream().cuda_stream)
-        self.f = torch.zeros((self.n, 3), dtype=torch.float64, device=self.dev)
-        self.f.index_add_(0, self.owner, self.fall)          # reverse communication
+        self.ctx.compute_device(self.xall, self.types_all, self.fall, eflag=1, vflag=self.vflag, ev_t=self.ev,
+                                stream=self.st)
+        self.ghosts.reverse(self.fall, stream=self.st)
 
-    # ---- one velocity-Verlet step ---------------------------------------------------------------------
+    # ---- one velocity-Verlet step ------------------------------------------------------------------------------
     def step(self, dt):
-        k = 0.5 * dt * FTM2V / self.mass
-        self.v.add_(self.f, alpha=k)
-        self.x.add_(self.v, alpha=dt)
+        dtf = 0.5 * dt * FTM2V
+        capi.nve_initial(self.n, self.xall, self.v, self.fall, self.types_all, self.inv_mass_t, dtf, dt, stream=self.st)
         self.steps_since_build += 1
         need = self.steps_since_build >= self.every
-        if not need and self.steps_since_build % 4 == 0:   # half-skin criterion, on the device
-            d2 = ((self.x - self.x_at_build) ** 2).sum(1).max()
-            need = bool(d2 > (0.5 * (self.cut - self.rc)) ** 2)
+        if not need and self.check_every and self.steps_since_build % self.check_every == 0:   # half-skin criterion
+            capi.nve_monitor(self.n, self.xall, self.x_ref, self.v, self.types_all, self.mass_t, self.mon, stream=self.st)
+            need = bool(self.mon[0].item() > (0.5 * (self.cut - self.rc)) ** 2)
         if need:
             self._reneighbor()
         self._forces()
-        self.v.add_(self.f, alpha=k)
+        capi.nve_final(self.n, self.v, self.fall, self.types_all, self.inv_mass_t, dtf, stream=self.st)
 
     def total_energy(self):
-        ke = 0.5 * MVV2E * self.mass * float((self.v ** 2).sum().item())
-        return float(self.ev[0].item()) + ke
+        capi.nve_monitor(self.n, self.xall, self.x_ref, self.v, self.types_all, self.mass_t, self.mon, stream=self.st)
+        m = self.mon.cpu().numpy()
+        return float(self.ev[0].item()) + 0.5 * MVV2E * float(m[1])

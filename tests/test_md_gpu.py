@@ -16,6 +16,13 @@ KB = 8.617343e-5
 MASS = 183.84
 
 
+def _wrapped_diff(a, b, box):
+    """max |a - b| modulo the box (the device driver wraps owned atoms into the box at every re-neighbouring)"""
+    d = a - b
+    d -= np.asarray(box) * np.round(d / np.asarray(box))
+    return float(np.abs(d).max())
+
+
 def _run(force_fn, pos, box, vel, nsteps, dt):
     e_tot = []
     f, e = force_fn(pos)
@@ -89,7 +96,7 @@ def test_device_resident_nve_matches_host_driven_loop():
         eg.append(md.total_energy())
     pc, vc, ec = _run(cpu_force, pos0.copy(), box, vel0.copy(), 10, 1e-3)
     assert md.builds >= 4                                   # re-neighboured on the device along the way
-    assert np.abs(md.x.cpu().numpy() - pc).max() < 1e-10 and np.abs(md.v.cpu().numpy() - vc).max() < 1e-9
+    assert _wrapped_diff(md.x.cpu().numpy(), pc, box) < 1e-10 and np.abs(md.v.cpu().numpy() - vc).max() < 1e-9
     assert np.abs(np.array(eg) - ec).max() < 1e-8
 
 
@@ -124,6 +131,59 @@ def test_device_resident_nve_level16_follows_oracle():
         eg.append(md.total_energy())
     pc, vc, ec = _run(cpu_force, pos0.copy(), box, vel0.copy(), 30, 2.5e-4)
     assert md.builds >= 6
-    assert np.abs(md.x.cpu().numpy() - pc).max() < 1e-9 and np.abs(md.v.cpu().numpy() - vc).max() < 1e-7
+    assert _wrapped_diff(md.x.cpu().numpy(), pc, box) < 1e-9 and np.abs(md.v.cpu().numpy() - vc).max() < 1e-7
     assert np.abs(np.array(eg) - ec).max() < 1e-7
     assert abs(float(md.v.mean())) < 1e-9            # momentum conserved (forces sum to zero)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ncell,cut", [((4, 4, 4), 7.0), ((3, 5, 4), 5.5), ((8, 8, 8), 7.0)])
+def test_device_ghost_images_match_host_construction(ncell, cut):
+    """mtp_ghosts_build against driver.make_ghosts: the same set of (owner, image position) pairs, the owned atoms
+    wrapped into the box; forward refresh and reverse fold against numpy."""
+    import torch
+    from lammps_mtp_kokkos_amd.driver import make_ghosts
+    pos, box = mtpgen.bcc_lattice(*ncell)
+    rng = np.random.default_rng(21)
+    pos = pos + rng.normal(0, 0.3, pos.shape) + np.array([40.0, -13.0, 0.2]) * (rng.random((len(pos), 1)) < 0.1)
+    n = len(pos)
+    dev = torch.device("cuda:0")
+    st = capi.use_private_torch_stream(dev).cuda_stream
+    g = capi.Ghosts(0)
+    x = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    x.copy_(torch.from_numpy(pos))
+    with pytest.raises(capi.MtpError) as ei:       # no room for ghosts: the size needed is reported
+        g.build(x, n, box, cut, stream=st)
+    assert ei.value.code == -24 and g.nall > n
+    xa = torch.zeros((g.nall, 3), dtype=torch.float64, device=dev)
+    xa[:n] = torch.from_numpy(pos)
+    nall = g.build(xa, n, box, cut, stream=st)
+    got = xa.cpu().numpy()
+    wrapped = pos - np.floor(pos / box) * box
+    assert np.abs(got[:n] - wrapped).max() < 1e-12 and (got[:n] >= 0).all() and (got[:n] < box).all()
+    want_x, want_owner = make_ghosts(wrapped, box, cut)
+    assert nall == len(want_x)
+    key = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+    assert np.abs(key(np.round(got[n:], 9)) - key(np.round(want_x[n:], 9))).max() < 1e-9
+    # forward: ghosts follow their owners; reverse: ghost rows add onto owner rows
+    ty = torch.zeros(nall, dtype=torch.int32, device=dev)
+    ty[:n] = torch.from_numpy(rng.integers(1, 4, n).astype(np.int32))
+    g.types(ty, stream=st)
+    moved = got.copy()
+    moved[:n] += rng.normal(0, 0.05, (n, 3))
+    xa[:n] = torch.from_numpy(moved[:n])
+    g.forward(xa, stream=st)
+    f_np = rng.normal(size=(nall, 3))
+    f = torch.from_numpy(f_np.copy()).to(dev)
+    g.reverse(f, stream=st)
+    torch.cuda.synchronize()
+    new = xa.cpu().numpy()
+    d = new[n:] - got[n:]                      # every ghost moved exactly as its owner did
+    tyh = ty.cpu().numpy()
+    # recover owners from the types + displacement: each ghost's displacement equals one owned atom's displacement
+    disp = moved[:n] - got[:n]
+    tree_owner = np.array([int(np.argmin(np.abs(disp - dk).sum(1))) for dk in d])
+    assert np.abs(disp[tree_owner] - d).max() < 1e-12 and np.array_equal(tyh[n:], tyh[:n][tree_owner])
+    want_f = f_np[:n].copy()
+    np.add.at(want_f, tree_owner, f_np[n:])
+    assert np.abs(f.cpu().numpy()[:n] - want_f).max() < 1e-12
