@@ -164,6 +164,12 @@ int mtp_cfg_grade(const mtp_potential *pot, const double *coeff_ders, double *gr
 /* introspection for benchmarks: LDS bytes per wavefront, wavefronts per workgroup, grid */
 int mtp_context_launch_info(const mtp_context *ctx, int32_t *lds_bytes_per_wave, int32_t *waves_per_block,
                             int32_t *grid_blocks, int32_t *neighbor_tile);
+/* Deterministic force sums (tests, reproducible goldens; SURVEY.md section 5 "deterministic-reduction mode"): the
+ * scatter f_j -= F_ij and the per-atom totals are accumulated as 64-bit fixed-point integers (2^-40 eV/A, |f| < 2^23)
+ * and converted once, so two calls on the same input return the same bits; energy and virial are folded in a fixed
+ * order in either mode.  Default off: native fp64 HBM atomics, whose sums depend on arrival order in the last bits
+ * (as the reference's own Kokkos atomics do, KOKKOS/pair_mtp_kokkos.cpp:602-605). */
+int mtp_context_set_deterministic(mtp_context *ctx, int enable);
 /* register build the planner chose (2 or 3 wavefronts per SIMD) and whether the per-atom LDS image uses the
  * "rebuild" layout (radial tables built twice, moments overlaying them) */
 int mtp_context_plan_info(const mtp_context *ctx, int32_t *waves_per_simd, int32_t *rebuild_tables);

@@ -30,6 +30,7 @@ EXPORTS = [
     "mtp_halo_reverse_end", "mtp_halo_reverse", "mtp_halo_allreduce",
     "mtp_ghosts_create", "mtp_ghosts_destroy", "mtp_ghosts_last_error", "mtp_ghosts_build", "mtp_ghosts_forward",
     "mtp_ghosts_reverse", "mtp_ghosts_types", "mtp_nve_initial", "mtp_nve_final", "mtp_nve_monitor",
+    "mtp_context_set_deterministic",
 ]
 HALO_ID_BYTES = 128
 REDUCE_SUM, REDUCE_MAX = 0, 1
@@ -281,6 +282,9 @@ class Context:
         self._check(lib().mtp_context_launch_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return dict(lds_bytes_per_wave=a.value, waves_per_block=b.value, grid_blocks=c.value,
                     neighbor_tile=d.value)
+
+    def set_deterministic(self, on=True):
+        self._check(lib().mtp_context_set_deterministic(self.h, int(on)))
 
     def set_timing(self, on=True):
         self._check(lib().mtp_context_set_timing(self.h, int(on)))

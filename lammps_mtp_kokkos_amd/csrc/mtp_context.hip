@@ -86,6 +86,8 @@ struct mtp_context {
   std::vector<double> h_tmp;
   // workspaces
   DevBuf<double> d_ev_slots, d_ev, d_maxg;
+  DevBuf<long long> d_fq;      // deterministic mode: fixed-point force accumulators, kept zeroed between calls
+  bool deterministic = false;
   DevBuf<int> d_err;
   DevBuf<unsigned long long> d_stamps;
   // launch geometry
@@ -792,6 +794,7 @@ int mtp_compute_device_rows(mtp_context *c, void *stream, int row_begin, int row
   p.x = d_x;
   p.type = d_type;
   p.f = d_f;
+  p.fq = nullptr;
   p.eatom = d_eatom;
   p.vatom = d_vatom;
   p.eflag = eflag;
@@ -838,7 +841,16 @@ int mtp_compute_device_rows(mtp_context *c, void *stream, int row_begin, int row
       }
       HIP_CHECK(hipEventRecord(c->ev0, st));
     }
+    if (c->deterministic && row_count > 0) {
+      const size_t n3 = 3 * (size_t) c->nall;
+      if (c->d_fq.cap < n3) {
+        c->d_fq.reserve(n3);
+        HIP_CHECK(hipMemsetAsync(c->d_fq.ptr, 0, n3 * sizeof(long long), st));
+      }
+      p.fq = c->d_fq.ptr;
+    }
     if (row_count > 0) HIP_CHECK(mtp_launch_wave_kernel(p, grid_for(L), L.wpb, L.lds_bytes, st));
+    if (p.fq) HIP_CHECK(mtp_launch_fixed_to_force(p.fq, d_f, c->nall, st));
     if (c->timing) {
       HIP_CHECK(hipEventRecord(c->ev1, st));
       c->timed = true;
@@ -993,6 +1005,13 @@ int mtp_debug_read_stamps(mtp_context *c, unsigned long long *out16)
   if (!c || !out16) return MTP_ERR_ARG;
   if (hipMemcpy(out16, c->d_stamps.ptr, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return MTP_ERR_DEVICE;
   (void) hipMemset(c->d_stamps.ptr, 0, 16 * sizeof(unsigned long long));
+  return MTP_OK;
+}
+
+int mtp_context_set_deterministic(mtp_context *c, int enable)
+{
+  if (!c) return MTP_ERR_ARG;
+  c->deterministic = enable != 0;
   return MTP_OK;
 }
 

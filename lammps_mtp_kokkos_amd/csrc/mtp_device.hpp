@@ -6,7 +6,8 @@
 #include <cstddef>
 #include <cstdint>
 
-#define MTP_EV_SLOTS 1024   // per-wave energy/virial tally slots (8 doubles each)
+#define MTP_EV_SLOTS 4096   // per-wave energy/virial tally slots (8 doubles each); >= wavefronts of a launch (256 CUs x 12), so
+                            // every slot has one writer and the folded sums do not depend on timing
 #define MTP_MAX_WPB 12      // wavefronts per workgroup: 8 (512 threads) in the 2-per-SIMD build, 12 in the 3-per-SIMD build
 #define MTP_PITCH 33        // doubles per row of the per-wavefront LDS tables (32 neighbour columns + 1: odd pitch)
 #define MTP_PSTRIDE 12      // slot ids per mu in the LDS blob (nu = 0..11, -1 padded)
@@ -59,6 +60,7 @@ struct MtpDevParams {
   const int *type;         // [nall] 1-based
   // outputs
   double *f;               // [nall][3] accumulated
+  long long *fq;           // deterministic mode: [nall][3] fixed-point force accumulators (else null)
   double *eatom;           // [nall] or null
   double *vatom;           // [nall][6] or null
   double *ev_slots;        // [MTP_EV_SLOTS][8]
@@ -98,6 +100,7 @@ int mtp_pick_fwd_shape(int nblk, int *KL, int *NB);
 hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);
 bool mtp_wave_kernel_has_wps3(int nfb, int P);
 hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st);
+hipError_t mtp_launch_fixed_to_force(long long *fq, double *f, int nall, hipStream_t st);
 // radial block of cvec from dbasic (grade calls, after the force kernel)
 hipError_t mtp_launch_cvec_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);
 // grades[ilist[ii]] = max_r |sum_c cvec[ii][c] Ainv[r][c]| (f64 MFMA), running maximum into max_grade;

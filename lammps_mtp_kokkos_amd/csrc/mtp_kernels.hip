@@ -66,6 +66,16 @@ static __device__ __forceinline__ KP kp_fresh()
 #define KP_FRESH() ((void) 0)
 #endif
 
+// f[idx] += v.  Default: native fp64 HBM atomics (the sum depends on the arrival order in the last bits).
+// Deterministic mode (mtp_context_set_deterministic, tests / reproducible goldens): the contributions are added as
+// 64-bit fixed-point integers (2^-40 eV/A resolution, |f| < 2^23), which commute exactly, and converted once at the end.
+#define MTP_FIXED_SCALE 1099511627776.0   // 2^40
+static __device__ __forceinline__ void force_add(KP kp, size_t idx, double v)
+{
+  if (kp->fq) atomicAdd(reinterpret_cast<unsigned long long *>(kp->fq) + idx, (unsigned long long) __double2ll_rn(v * MTP_FIXED_SCALE));
+  else unsafeAtomicAdd(&kp->f[idx], v);
+}
+
 template <int PITCH> struct WaveLds {
   static constexpr int NT = 32;   // neighbours per tile; the row pitch (33 doubles: odd, so the 32 lanes of a half-wavefront
                                   // reading 32 different rows of one column hit 32 different 8-byte banks) is the template parameter
@@ -856,8 +866,8 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
         if (valid) {
           const size_t j = (size_t) w.nbj[n];
 #ifndef MTP_EXP_NOSCATTER   // timing experiment only (wrong results)
-          unsafeAtomicAdd(&kp->f[3 * j + (part ? 2 : 0)], -Fa);   // pair_mtp.cpp:252-254
-          if (part == 0) unsafeAtomicAdd(&kp->f[3 * j + 1], -Fy);
+          force_add(kp, 3 * j + (part ? 2 : 0), -Fa);   // pair_mtp.cpp:252-254
+          if (part == 0) force_add(kp, 3 * j + 1, -Fy);
 #else
           if (Fa + Fy == 12345.678) kp->f[3 * j] = Fa;   // keeps the values live
 #endif
@@ -914,7 +924,7 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     tot = pair_sum32(pair_sum16(tot));
     if (lane < 9) {
       if (lane < 3) {
-        unsafeAtomicAdd(&kp->f[3 * (size_t) i + lane], tot);   // pair_mtp.cpp:248-250
+        force_add(kp, 3 * (size_t) i + lane, tot);   // pair_mtp.cpp:248-250
       } else if (v_per_atom) {
         tally += tot;
         if ((kp->vflag & 4) && kp->vatom) kp->vatom[6 * (size_t) i + (lane - 3)] += tot;
@@ -945,6 +955,18 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
   if (lane >= 3 && lane <= 9 && tally != 0.0) {
     double *slot = kp->ev_slots + 8 * (size_t) ((blockIdx.x * wpb + wave) % MTP_EV_SLOTS);
     unsafeAtomicAdd(&slot[lane == 9 ? 0 : lane - 2], tally);
+  }
+}
+
+// f[k] += fq[k] 2^-40, fq[k] = 0: the end of a deterministic-mode force call
+__global__ void __launch_bounds__(256) mtp_fixed_to_force(long long *__restrict__ fq, double *__restrict__ f, int n3)
+{
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n3) return;
+  const long long q = fq[e];
+  if (q != 0) {
+    f[e] += (double) q * (1.0 / MTP_FIXED_SCALE);
+    fq[e] = 0;
   }
 }
 
@@ -1253,6 +1275,12 @@ hipError_t mtp_launch_colsum_kernel(const double *cvec, int cpad, int C, int inu
 {
   hipLaunchKernelGGL(mtp_colsum_kernel, dim3((C + 255) / 256, (inum + 255) / 256), dim3(256), 0, st, cvec, cpad, C, inum,
                      coeff_ders);
+  return hipGetLastError();
+}
+
+hipError_t mtp_launch_fixed_to_force(long long *fq, double *f, int nall, hipStream_t st)
+{
+  hipLaunchKernelGGL(mtp_fixed_to_force, dim3((3 * nall + 255) / 256), dim3(256), 0, st, fq, f, 3 * nall);
   return hipGetLastError();
 }
 

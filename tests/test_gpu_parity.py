@@ -439,3 +439,23 @@ def test_golden_grades():
         else:
             _close(r["grades"], g["grades"], n + " grades", rtol=1e-9)
             assert abs(r["max_grade"] - float(g["max_grade"])) <= 1e-9 * max(1.0, float(g["max_grade"]))
+
+
+def test_deterministic_mode_is_bitwise_reproducible():
+    """mtp_context_set_deterministic: fixed-point force accumulation -> the same bits on every call (the default fp64
+    atomics agree to rounding only), still within tolerance of the oracle."""
+    s = _system((5, 5, 5))
+    path = os.path.join(POT, "W_L16.mtp")
+    pot = capi.Potential(path)
+    ctx = capi.Context(pot, 0)
+    ctx.set_deterministic(True)
+    ctx.set_neighbors(s.ilist, s.first, s.neigh, s.nall)
+    runs = [ctx.compute(s.x, s.types) for _ in range(4)]
+    for r in runs[1:]:
+        assert np.array_equal(r["f"], runs[0]["f"])
+        assert r["energy"] == runs[0]["energy"] and np.array_equal(r["virial"], runs[0]["virial"])
+        assert np.array_equal(r["eatom"], runs[0]["eatom"]) and np.array_equal(r["vatom"], runs[0]["vatom"])
+    want = _oracle(path).compute(s.x, s.types, s.ilist, s.first, s.neigh)
+    _close(runs[0]["f"], want["f"], "deterministic forces")
+    ctx.set_deterministic(False)
+    _close(ctx.compute(s.x, s.types)["f"], runs[0]["f"], "atomic vs fixed-point forces", atol=1e-10)
