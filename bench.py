@@ -259,7 +259,7 @@ def main():
             traffic, pmc_block = None, None
 
     # ---- CPU baseline: the oracle (a port of the reference CPU path), rank 0, N = 1 -----------------
-    # leg (i) one thread; leg (ii) every host core: threads over atoms with private force arrays (oracle/mtp_oracle_mt.c)
+    # leg (i) one thread; leg (ii) every host core: threads over atoms adding into one force array (oracle/mtp_oracle_mt.c)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.pyoracle import Oracle

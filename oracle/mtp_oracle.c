@@ -375,6 +375,25 @@ double mtp_oracle_grade(const mtp_oracle_model *m, const double *c)
 /* One implementation serves both compute paths; `ext` switches on the extras of
  * pair_mtp_extrapolation.cpp (radial Jacobian :193-198, candidate vector :235-252 and
  * :323-329, grade :332-336).  With ext == 0 it is pair_mtp.cpp:72-280 line for line. */
+/* f += v as the reference writes it (pair_mtp.cpp:248-254); when several threads of the cpu_baseline driver
+ * (mtp_oracle_mt.c) share one force array the same add is made atomic (compare-and-swap on the bit pattern) */
+static _Thread_local int shared_force_array = 0;
+void mtp_oracle_share_force_array(int on) { shared_force_array = on; }
+static inline void force_add(double *p, double v)
+{
+  if (!shared_force_array) {
+    *p += v;
+    return;
+  }
+  unsigned long long *q = (unsigned long long *) p, old = __atomic_load_n(q, __ATOMIC_RELAXED), neu;
+  do {
+    double d;
+    memcpy(&d, &old, sizeof d);
+    d += v;
+    memcpy(&neu, &d, sizeof d);
+  } while (!__atomic_compare_exchange_n(q, &old, neu, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+}
+
 static int compute_impl(const mtp_oracle_model *m, int ext, int inum, const int *ilist,
                         const int *first, const int *neigh, const double *x, const int *type,
                         int eflag, int vflag, double *f, double *eng_vdwl, double *eatom,
@@ -536,12 +555,12 @@ static int compute_impl(const mtp_oracle_model *m, int ext, int inum, const int 
       double temp_force[3] = {0, 0, 0};
       for (int k = 0; k < B; k++)
         for (int a = 0; a < 3; a++) temp_force[a] += ders[k] * jac[3 * k + a];
-      f[3 * i + 0] += temp_force[0];
-      f[3 * i + 1] += temp_force[1];
-      f[3 * i + 2] += temp_force[2];
-      f[3 * j + 0] -= temp_force[0];
-      f[3 * j + 1] -= temp_force[1];
-      f[3 * j + 2] -= temp_force[2];
+      force_add(&f[3 * i + 0], temp_force[0]);
+      force_add(&f[3 * i + 1], temp_force[1]);
+      force_add(&f[3 * i + 2], temp_force[2]);
+      force_add(&f[3 * j + 0], -temp_force[0]);
+      force_add(&f[3 * j + 1], -temp_force[1]);
+      force_add(&f[3 * j + 2], -temp_force[2]);
       if (vflag) {
         const double r[3] = {x[3 * j] - xi[0], x[3 * j + 1] - xi[1], x[3 * j + 2] - xi[2]};
         virial[0] -= temp_force[0] * r[0];

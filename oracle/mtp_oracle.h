@@ -69,8 +69,11 @@ int mtp_oracle_compute(const mtp_oracle_model *m, int inum, const int *ilist, co
                        const int *neigh, const double *x, const int *type, int eflag, int vflag,
                        double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom);
 
-/* The same, threads over atoms (mtp_oracle_mt.c): nthreads slices of ilist, private force arrays, summed at the
- * end.  bench.py's cpu_baseline leg (ii); nall = rows of x / f. */
+/* (internal to the threaded driver: this thread's compute calls add into a force array shared with other threads) */
+void mtp_oracle_share_force_array(int on);
+
+/* The same, threads over atoms (mtp_oracle_mt.c): nthreads slices of ilist adding into the one force array
+ * with atomic adds.  bench.py's cpu_baseline leg (ii); nall = rows of x / f. */
 int mtp_oracle_compute_mt(const mtp_oracle_model *m, int nthreads, int nall, int inum, const int *ilist,
                           const int *first, const int *neigh, const double *x, const int *type, int eflag,
                           int vflag, double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom);

@@ -89,7 +89,7 @@ class Oracle:
         return v, d
 
     def compute_mt(self, nthreads, x, types, ilist, first, neigh, eflag=3, vflag=4):
-        """compute() with threads over atoms (private force arrays, summed at the end): the cpu_baseline leg that
+        """compute() with threads over atoms (atomic adds into the one force array): the cpu_baseline leg that
         uses every host core."""
         x = np.ascontiguousarray(x, dtype=np.float64)
         types = np.ascontiguousarray(types, dtype=np.int32)
