@@ -289,7 +289,7 @@ def main():
                 tmt += time.perf_counter() - c0
                 mp_ += 1
             cpu.update({"value": plan.nlocal * mp_ / tmt, "cores": nthr, "value_1_thread": one,
-                        "sample": "%d passes over all %d atoms, %d threads over atoms with private force arrays "
+                        "sample": "%d passes over all %d atoms, %d threads over atoms adding into one force array "
                                   "(oracle/mtp_oracle_mt.c), %.1f s; 1 thread: %s" % (mp_, plan.nlocal, nthr, tmt, cpu["sample"])})
         # parity of the timed configuration, sampled: site energies of the sub-list
         ea = torch.zeros(plan.nall, dtype=torch.float64, device=dev)
