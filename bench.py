@@ -166,19 +166,12 @@ def main():
     kw = dict(eflag=EFLAG, vflag=VFLAG, grade=grade, grades_t=grades_t, maxg_t=maxg_t, stream=stream)
 
     def step():
+        if world > 1 and halo_kind == "native":     # zero f, forward halo || rows A, rows B, reverse halo || rows C, fold
+            halo.force_step(ctx, (n_a, n_b, n_c), x, ty, f, ev_t=ev, **kw)
+            return
         f.zero_()
         if world == 1:
             ctx.compute_device(x, ty, f, ev_t=ev, **kw)
-        elif halo_kind == "native":
-            halo.forward_begin(x, stream)
-            if n_a:
-                ctx.compute_device_rows(0, n_a, False, x, ty, f, **kw)
-            halo.forward_end(stream)
-            ctx.compute_device_rows(n_a, n_b, n_c == 0, x, ty, f, ev_t=ev, **kw)
-            halo.reverse_begin(f, stream)
-            if n_c:
-                ctx.compute_device_rows(n_a + n_b, n_c, True, x, ty, f, ev_t=ev, **kw)
-            halo.reverse_end(f, stream)
         else:
             h = halo.forward_begin(x)
             if n_a:

@@ -101,7 +101,8 @@ struct mtp_context {
     int wps = 2;
     bool rows_lds = false;
     size_t lds_bytes = 0;
-  } lp[2];   // [0] force calls (wavefront per atom), [1] candidate-vector kernel of grade calls
+  } lp[3];   // [0] force calls (wavefront per atom), [1] candidate-vector kernel of grade calls, [2] the fused kernel's
+             // grade instantiation (planned without the 3-per-SIMD build: at 168 VGPRs it spills 52 dwords and is slower)
   DevBuf<double> d_cvec, d_ainv_pad, d_ainv_tiled, d_dbasic;
   int cpad = 0, dpad = 0;
   // timing
@@ -127,8 +128,8 @@ void mtp_context::plan()
   const size_t LDS = 160 * 1024;
   size_t blob = (size_t) blob_bytes_norows;   // without the packed rows; a plan adds them when they come for free
   const int nt = 32;
-  {   // [0] fused force kernel (also its grade instantiation, which only adds two HBM writes)
-    LaunchPlan &L = lp[0];
+  for (int which : {0, 2}) {   // [0] fused force kernel, [2] its grade instantiation
+    LaunchPlan &L = lp[which];
     L.tab_rows = 2 * p.slot_count + 3 * P;
     L.g_doubles = 0;
     const int d_doubles = A;
@@ -217,6 +218,7 @@ void mtp_context::plan()
     bool has3 = mtp_wave_kernel_has_wps3(p.fwd_block_count, P);
     if (const char *e = std::getenv("MTP_WPS")) has3 = has3 && std::atoi(e) == 3;   // tuning override: 2 = never, 3 = whenever it fits
     else has3 = has3 && !fine;
+    if (which == 2 && !std::getenv("MTP_GRADE_WPS3")) has3 = false;   // (MTP_GRADE_WPS3=1: timing experiments)
     const Layout *pick = nullptr;
     int wps = 2, w3 = 0, pick_waves = 0;
     for (const Layout *y : cands) {
@@ -801,12 +803,23 @@ int mtp_compute_device_rows(mtp_context *c, void *stream, int row_begin, int row
   p.vflag = vflag;
   p.grade_flag = grade_flag ? 1 : 0;
   p.xcd_map = c->xcd_map && row_count >= 8 * 64 ? 1 : 0;
-  const mtp_context::LaunchPlan &L = c->lp[0];
-  // the planned grid covers the whole list; a row range needs no more workgroups than it has wavefronts' worth of rows
-  // (kept a multiple of 8 where possible: the XCD-aware atom map wants whole rounds of the 8 XCDs)
-  auto grid_for = [&](const mtp_context::LaunchPlan &lp_) {
-    int g = std::min(lp_.grid, (row_count + lp_.wpb - 1) / lp_.wpb);
-    if (g >= 8) g = std::min(lp_.grid, (g + 7) / 8 * 8);
+  const mtp_context::LaunchPlan &L = c->lp[grade_flag ? 2 : 0];
+  // The plan covers the whole list.  A row range too short to fill it (the interior / boundary pieces of a small
+  // domain, strong scaling) runs in smaller workgroups, so that its atoms spread over all CUs instead of filling a
+  // few of them: per-atom latency, not throughput, is what such a launch waits for.
+  int wpb_launch = L.wpb;
+  const int waves_per_cu = L.wpb * std::max(1, L.grid / std::max(1, c->num_cus));
+  if (row_count < c->num_cus * waves_per_cu && L.grid >= c->num_cus) {
+    const int small = L.wps == 3 ? 4 : 2;   // (multiples of 4 keep the SIMDs balanced at 3 per SIMD)
+    if (small < wpb_launch) wpb_launch = small;
+  }
+  const size_t blob_launch = L.rows_lds ? (size_t) c->blob_bytes_rows : (size_t) c->blob_bytes_norows;
+  const size_t lds_launch = blob_launch + (size_t) wpb_launch * L.wave_doubles * 8;
+  auto grid_for = [&](const mtp_context::LaunchPlan &lp_, int wpb_) {
+    int g = (row_count + wpb_ - 1) / wpb_;
+    if (wpb_ == lp_.wpb) g = std::min(lp_.grid, g);
+    else g = std::min(g, c->num_cus * (int) std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds_launch, 1)));
+    if (g >= 8) g = (g + 7) / 8 * 8;   // whole rounds of the 8 XCDs for the XCD-aware atom map
     return std::max(1, g);
   };
   p.tab_rows = L.tab_rows;
@@ -849,7 +862,7 @@ int mtp_compute_device_rows(mtp_context *c, void *stream, int row_begin, int row
       }
       p.fq = c->d_fq.ptr;
     }
-    if (row_count > 0) HIP_CHECK(mtp_launch_wave_kernel(p, grid_for(L), L.wpb, L.lds_bytes, st));
+    if (row_count > 0) HIP_CHECK(mtp_launch_wave_kernel(p, grid_for(L, wpb_launch), wpb_launch, lds_launch, st));
     if (p.fq) HIP_CHECK(mtp_launch_fixed_to_force(p.fq, d_f, c->nall, st));
     if (c->timing) {
       HIP_CHECK(hipEventRecord(c->ev1, st));
@@ -864,7 +877,8 @@ int mtp_compute_device_rows(mtp_context *c, void *stream, int row_begin, int row
         pc.rows_in_lds = 0;
         pc.wave_doubles = c->lp[1].wave_doubles;
         pc.tab_rows = c->lp[1].tab_rows;
-        HIP_CHECK(mtp_launch_cvec_kernel(pc, grid_for(c->lp[1]), c->lp[1].wpb, c->lp[1].lds_bytes, st));
+        HIP_CHECK(mtp_launch_cvec_kernel(pc, std::max(1, std::min(c->lp[1].grid, (row_count + c->lp[1].wpb - 1) / c->lp[1].wpb)),
+                                         c->lp[1].wpb, c->lp[1].lds_bytes, st));
       }
       const double *cv = c->d_cvec.ptr + (size_t) row_begin * c->cpad;
       if (cfg)

@@ -296,6 +296,35 @@ int mtp_halo_reverse(mtp_halo *h, void *stream, double *d_f)
   return rc != MTP_OK ? rc : mtp_halo_reverse_end(h, stream, d_f);
 }
 
+// One domain-decomposed force call with both exchanges overlapped (rows of the installed list ordered interior A |
+// boundary | interior C): zero f; forward halo || rows A; boundary rows; reverse halo || rows C; fold.  One entry
+// point instead of eight, so a driver's per-call overhead is paid once per step.
+int mtp_halo_force_step(mtp_halo *h, mtp_context *ctx, void *stream, int rows_a, int rows_b, int rows_c, double *d_x,
+                        const int *d_type, int eflag, int vflag, int grade_flag, double *d_f, double *d_eatom,
+                        double *d_vatom, double *d_ev, double *d_grades, double *d_max_grade, double *d_coeff_ders)
+{
+  if (!h || !ctx || !d_x || !d_f || rows_a < 0 || rows_b < 0 || rows_c < 0) return MTP_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(d_f, 0, 3 * (size_t) (h->nlocal + h->nghost) * sizeof(double), st) != hipSuccess) {
+    h->last_error = "hipMemsetAsync(f) failed";
+    return MTP_ERR_DEVICE;
+  }
+  int rc = mtp_halo_forward_begin(h, stream, d_x);
+  if (rc == MTP_OK && rows_a > 0)
+    rc = mtp_compute_device_rows(ctx, stream, 0, rows_a, 0, d_x, d_type, eflag, vflag, grade_flag, d_f, d_eatom, d_vatom,
+                                 d_ev, d_grades, d_max_grade, d_coeff_ders);
+  if (rc == MTP_OK) rc = mtp_halo_forward_end(h, stream);
+  if (rc == MTP_OK)
+    rc = mtp_compute_device_rows(ctx, stream, rows_a, rows_b, rows_c == 0, d_x, d_type, eflag, vflag, grade_flag, d_f,
+                                 d_eatom, d_vatom, d_ev, d_grades, d_max_grade, d_coeff_ders);
+  if (rc == MTP_OK) rc = mtp_halo_reverse_begin(h, stream, d_f);
+  if (rc == MTP_OK && rows_c > 0)
+    rc = mtp_compute_device_rows(ctx, stream, rows_a + rows_b, rows_c, 1, d_x, d_type, eflag, vflag, grade_flag, d_f,
+                                 d_eatom, d_vatom, d_ev, d_grades, d_max_grade, d_coeff_ders);
+  if (rc == MTP_OK) rc = mtp_halo_reverse_end(h, stream, d_f);
+  return rc;
+}
+
 int mtp_halo_allreduce(mtp_halo *h, void *stream, double *d_buf, int count, int op)
 {
   if (!h || !d_buf || count < 0 || (op != MTP_REDUCE_SUM && op != MTP_REDUCE_MAX)) return MTP_ERR_ARG;

@@ -112,6 +112,15 @@ def test_overlapped_step_matches_single_shot_call_and_oracle(rank0, potential, g
         ctx.compute_device_rows(na + nb, nc, True, x, ty, f, ev_t=ev, **kw)
         halo.reverse_end(f, st)
     ctx.synchronize(st)
+    f_steps = f.clone()
+    ev_steps = ev.clone()
+    # ... and the same step through the single entry point (mtp_halo_force_step)
+    ev.zero_()
+    if grade:
+        mg.zero_()
+    halo.force_step(ctx, (na, nb, nc), x, ty, f, ev_t=ev, **kw)
+    ctx.synchronize(st)
+    assert (f - f_steps).abs().max().item() < 1e-11 and (ev - ev_steps).abs().max().item() < 1e-8
     x_all = np.concatenate([x_own, x_own[plan.send_idx] + plan.send_shift])
     o = Oracle(path, selection=grade)
     want = o.compute(x_all, plan.types, plan.ilist, plan.first, plan.neigh, eflag=3, vflag=1, extrapolation=grade,
