@@ -49,6 +49,11 @@ def info_launch_waves(ctx):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON record: everything else that libraries print there (RCCL's version
+    # banner at communicator creation, for one) goes to stderr.  The original stdout is kept for the record.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -118,7 +123,11 @@ def main():
     ctx.set_variant(dict(auto=0, large=1, small=2)[args.variant])
     # N > 1: the rows are ordered interior | boundary | interior (atoms whose list holds no ghost are "interior")
     halo_kind = os.environ.get("MTP_BENCH_HALO", "native" if backend == "nccl" else "torch")
-    use_rows = world > 1 and os.environ.get("MTP_BENCH_OVERLAP", "1") != "0"
+    # MTP_BENCH_SELF_HALO=1 (rehearsal on one GPU): the N > 1 step -- library halo, three row ranges -- with this rank's
+    # own periodic images as its only peer, i.e. the per-step structure and overheads of a rank of a larger job
+    self_halo = world == 1 and os.environ.get("MTP_BENCH_SELF_HALO", "0") == "1"
+    decomposed = world > 1 or self_halo
+    use_rows = decomposed and os.environ.get("MTP_BENCH_OVERLAP", "1") != "0"
     if use_rows:
         ilist_np, first_np, neigh_np, (n_a, n_b, n_c) = overlap_order(plan)
     else:
@@ -140,7 +149,11 @@ def main():
 
     # the halo: the library's RCCL exchange (production), or the torch twin (gloo rehearsals on one GPU)
     halo, halo_info, halo_note = None, None, None
-    if world > 1:
+    if self_halo:
+        halo_kind = "native"
+        halo = capi.Halo(plan, devidx, capi.halo_unique_id())
+        halo_info = halo.comm_count()
+    elif world > 1:
         if halo_kind == "native":
             # every rank must end up on the same path: the outcome of the (collective) creation is agreed on below
             ok = 1
@@ -166,10 +179,10 @@ def main():
     kw = dict(eflag=EFLAG, vflag=VFLAG, grade=grade, grades_t=grades_t, maxg_t=maxg_t, stream=stream)
 
     def step():
-        if world > 1 and halo_kind == "native":     # zero f, forward halo || rows A, rows B, reverse halo || rows C, fold
+        if decomposed and halo_kind == "native":     # zero f, forward halo || rows A, rows B, reverse halo || rows C, fold
             halo.force_step(ctx, (n_a, n_b, n_c), x, ty, f, ev_t=ev, **kw)
             return
-        f.zero_()
+        capi.zero_async(f, stream)
         if world == 1:
             ctx.compute_device(x, ty, f, ev_t=ev, **kw)
         else:
@@ -362,7 +375,7 @@ def main():
                            % (halo_info["nranks"], halo_info["rccl_version"]) if halo_info else "torch all-to-all halo (%s)%s" % (
                                backend, "; " + halo_note if halo_note else ""),
                            ", rows interior|boundary|interior = %d|%d|%d overlap both exchanges" % (n_a, n_b, n_c) if use_rows else ""))
-                       if world > 1 else "single GPU",
+                       if decomposed else "single GPU",
                        "atoms_rank0": plan.nlocal, "ghosts_rank0": plan.nghost, "list_entries_rank0": int(plan.first[-1]),
                        "in_cutoff_pairs_rank0": jc_total, "launch": info,
                        "device_list_build_ms": list_build_ms},
@@ -381,7 +394,7 @@ def main():
             "whole_step": whole,
             "energy_per_atom_eV": energy_per_atom,
         }
-        print(json.dumps(line))
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

@@ -164,6 +164,9 @@ int mtp_cfg_grade(const mtp_potential *pot, const double *coeff_ders, double *gr
 /* introspection for benchmarks: LDS bytes per wavefront, wavefronts per workgroup, grid */
 int mtp_context_launch_info(const mtp_context *ctx, int32_t *lds_bytes_per_wave, int32_t *waves_per_block,
                             int32_t *grid_blocks, int32_t *neighbor_tile);
+/* d_p[0, n) = 0.0 in one kernel launch on `stream` (d_p 16-byte aligned): the "zero the force array" that precedes
+ * every force call (LAMMPS: Verlet::force_clear) without hipMemsetAsync's two fill kernels. */
+int mtp_zero_async(void *stream, double *d_p, long long n);
 /* Deterministic force sums (tests, reproducible goldens; SURVEY.md section 5 "deterministic-reduction mode"): the
  * scatter f_j -= F_ij and the per-atom totals are accumulated as 64-bit fixed-point integers (2^-40 eV/A, |f| < 2^23)
  * and converted once, so two calls on the same input return the same bits; energy and virial are folded in a fixed

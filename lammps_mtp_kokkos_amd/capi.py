@@ -30,7 +30,7 @@ EXPORTS = [
     "mtp_halo_reverse_end", "mtp_halo_reverse", "mtp_halo_allreduce", "mtp_halo_force_step",
     "mtp_ghosts_create", "mtp_ghosts_destroy", "mtp_ghosts_last_error", "mtp_ghosts_build", "mtp_ghosts_forward",
     "mtp_ghosts_reverse", "mtp_ghosts_types", "mtp_nve_initial", "mtp_nve_final", "mtp_nve_monitor",
-    "mtp_context_set_deterministic",
+    "mtp_context_set_deterministic", "mtp_zero_async",
 ]
 HALO_ID_BYTES = 128
 REDUCE_SUM, REDUCE_MAX = 0, 1
@@ -293,6 +293,13 @@ class Context:
         ms = C.c_float(0)
         self._check(lib().mtp_context_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
+
+
+def zero_async(t, stream=None):
+    """t[...] = 0 on `stream` in one kernel launch (fp64 tensor)"""
+    rc = lib().mtp_zero_async(C.c_void_p(stream) if stream else None, _ptr(t), C.c_longlong(t.numel()))
+    if rc:
+        raise MtpError(rc, "mtp_zero_async")
 
 
 def halo_unique_id():

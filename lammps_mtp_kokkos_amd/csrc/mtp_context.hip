@@ -1022,6 +1022,12 @@ int mtp_debug_read_stamps(mtp_context *c, unsigned long long *out16)
   return MTP_OK;
 }
 
+int mtp_zero_async(void *stream, double *d_p, long long n)
+{
+  if (n < 0 || (n > 0 && !d_p) || (reinterpret_cast<uintptr_t>(d_p) & 15u)) return MTP_ERR_ARG;
+  return mtp_launch_zero(d_p, (size_t) n, reinterpret_cast<hipStream_t>(stream)) == hipSuccess ? MTP_OK : MTP_ERR_DEVICE;
+}
+
 int mtp_context_set_deterministic(mtp_context *c, int enable)
 {
   if (!c) return MTP_ERR_ARG;

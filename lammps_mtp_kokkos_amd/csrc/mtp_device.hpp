@@ -101,6 +101,7 @@ hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size
 bool mtp_wave_kernel_has_wps3(int nfb, int P);
 hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st);
 hipError_t mtp_launch_fixed_to_force(long long *fq, double *f, int nall, hipStream_t st);
+hipError_t mtp_launch_zero(double *p, size_t n, hipStream_t st);
 // radial block of cvec from dbasic (grade calls, after the force kernel)
 hipError_t mtp_launch_cvec_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);
 // grades[ilist[ii]] = max_r |sum_c cvec[ii][c] Ainv[r][c]| (f64 MFMA), running maximum into max_grade;

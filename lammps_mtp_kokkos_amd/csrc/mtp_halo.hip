@@ -304,9 +304,8 @@ int mtp_halo_force_step(mtp_halo *h, mtp_context *ctx, void *stream, int rows_a,
                         double *d_vatom, double *d_ev, double *d_grades, double *d_max_grade, double *d_coeff_ders)
 {
   if (!h || !ctx || !d_x || !d_f || rows_a < 0 || rows_b < 0 || rows_c < 0) return MTP_ERR_ARG;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(d_f, 0, 3 * (size_t) (h->nlocal + h->nghost) * sizeof(double), st) != hipSuccess) {
-    h->last_error = "hipMemsetAsync(f) failed";
+  if (mtp_zero_async(stream, d_f, 3ll * (h->nlocal + h->nghost)) != MTP_OK) {
+    h->last_error = "zeroing f failed";
     return MTP_ERR_DEVICE;
   }
   int rc = mtp_halo_forward_begin(h, stream, d_x);

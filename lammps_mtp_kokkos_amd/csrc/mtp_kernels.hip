@@ -970,19 +970,35 @@ __global__ void __launch_bounds__(256) mtp_fixed_to_force(long long *__restrict_
   }
 }
 
-// folds the per-wave tally slots into ev[7] (accumulating) and clears them
-__global__ void mtp_ev_finish(double *ev_slots, double *ev)
+// folds the per-wave tally slots into ev[7] (accumulating) and clears them: one workgroup of 512 threads per
+// quantity, a fixed summation order (lane-strided partial sums, then a fixed tree), so the totals do not depend on timing
+__global__ void __launch_bounds__(512) mtp_ev_finish(double *ev_slots, double *ev)
 {
+  __shared__ double part[8];
   const int q = blockIdx.x;   // 0..6
   double s = 0.0;
-  for (int k = threadIdx.x; k < MTP_EV_SLOTS; k += 64) {
+  for (int k = threadIdx.x; k < MTP_EV_SLOTS; k += 512) {
     s += ev_slots[8 * (size_t) k + q];
     ev_slots[8 * (size_t) k + q] = 0.0;
   }
   s = wave_sum(s);
-  if (threadIdx.x == 0) ev[q] += s;
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) t += part[w];
+    ev[q] += t;
+  }
 }
 
+// f[0, n) = 0 in one launch (hipMemsetAsync splits into two fill kernels for sizes that are not multiples of its tile)
+__global__ void __launch_bounds__(256) mtp_zero_kernel(double2 *__restrict__ p, size_t n2, double *__restrict__ tail, int ntail)
+{
+  const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+  if (i < n2) p[i] = make_double2(0.0, 0.0);
+  if (i < (size_t) ntail) tail[i] = 0.0;
+}
 
 // ---- MaxVol grade: grades[i] = max_r | sum_c cvec[i][c] Ainv[r][c] |  (pair_mtp_extrapolation.cpp:347-358)
 // One inverse active set for every atom: a dense [atoms x C] x [C x C] fp64 contraction, done on
@@ -1286,6 +1302,15 @@ hipError_t mtp_launch_fixed_to_force(long long *fq, double *f, int nall, hipStre
 
 hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st)
 {
-  hipLaunchKernelGGL(mtp_ev_finish, dim3(7), dim3(64), 0, st, ev_slots, ev);
+  hipLaunchKernelGGL(mtp_ev_finish, dim3(7), dim3(512), 0, st, ev_slots, ev);
+  return hipGetLastError();
+}
+
+hipError_t mtp_launch_zero(double *p, size_t n, hipStream_t st)   // p 16-byte aligned (hipMalloc / torch allocations are)
+{
+  if (n == 0) return hipSuccess;
+  const size_t n2 = n / 2;
+  hipLaunchKernelGGL(mtp_zero_kernel, dim3((unsigned) ((std::max<size_t>(n2, 1) + 255) / 256)), dim3(256), 0, st,
+                     reinterpret_cast<double2 *>(p), n2, p + 2 * n2, (int) (n - 2 * n2));
   return hipGetLastError();
 }

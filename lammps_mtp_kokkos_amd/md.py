@@ -102,7 +102,7 @@ class DeviceNVE:
 
     def _forces(self):
         self.ghosts.forward(self.xall, stream=self.st)
-        self.fall[: self.nall].zero_()
+        capi.zero_async(self.fall[: self.nall], stream=self.st)
         self.ev.zero_()
         self.ctx.compute_device(self.xall, self.types_all, self.fall, eflag=1, vflag=self.vflag, ev_t=self.ev,
                                 stream=self.st)
