@@ -227,13 +227,17 @@ def sub_list(plan: HaloPlan, rows):
     return plan.ilist[rows].astype(np.int32), first, neigh.astype(np.int32)
 
 
-def overlap_order(plan: HaloPlan, frac_first=0.5):
-    """Neighbour list of the rank reordered for an overlapped step: rows [0, nA) and [nA + nB, nA + nB + nC) are
-    interior atoms (no ghost in their list), rows [nA, nA + nB) the boundary atoms.  The step then runs
-    forward-halo || rows A, boundary rows, reverse-halo || rows C (mtp_compute_device_rows).
+def overlap_order(plan: HaloPlan, round_atoms=3072):
+    """Neighbour list of the rank reordered for an overlapped step: rows [0, nA) and the last nC rows are interior
+    atoms (no ghost in their list); the rows in between hold the boundary atoms and whatever interior atoms are left.
+    The step then runs forward-halo || rows A, middle rows, reverse-halo || rows C (mtp_halo_force_step).  A and C
+    only have to outlast one exchange, so they get at most `round_atoms` atoms each (one wavefront per atom: 256 CUs
+    x 12 wavefronts fill the GPU once) -- every extra launch costs a partially filled last round of wavefronts.
     Returns (ilist, first, neigh, (nA, nB, nC))."""
     interior, boundary = split_interior(plan)
-    na = int(len(interior) * frac_first)
-    order = np.concatenate([interior[:na], boundary, interior[na:]]).astype(np.int64)
+    na = min(len(interior) // 2, int(round_atoms))
+    nc = na
+    order = np.concatenate([interior[:na], boundary, interior[na:len(interior) - nc],
+                            interior[len(interior) - nc:]]).astype(np.int64)
     ilist, first, neigh = sub_list(plan, order)
-    return ilist, first, neigh, (na, len(boundary), len(interior) - na)
+    return ilist, first, neigh, (na, len(order) - na - nc, nc)

@@ -94,11 +94,14 @@ def test_overlap_order_partitions_rows_into_interior_boundary_interior():
     from lammps_mtp_kokkos_amd.domain import overlap_order
     pos, box = mtpgen.bcc_lattice(8, 8, 8)
     plan = decompose(pos, box, None, 2, 1, 7.0)
-    ilist, first, neigh, (na, nb, nc) = overlap_order(plan)
-    assert na + nb + nc == plan.nlocal and sorted(ilist.tolist()) == list(range(plan.nlocal))
-    for r, i in enumerate(ilist):
-        row = neigh[first[r]:first[r + 1]]
-        want = plan.neigh[plan.first[i]:plan.first[i + 1]]
-        assert np.array_equal(row, want)
-        has_ghost = bool((row >= plan.nlocal).any())
-        assert has_ghost == (na <= r < na + nb)
+    for cap in (3072, 40):
+        ilist, first, neigh, (na, nb, nc) = overlap_order(plan, cap)
+        assert na + nb + nc == plan.nlocal and sorted(ilist.tolist()) == list(range(plan.nlocal))
+        assert na == nc and 0 < na <= cap
+        for r, i in enumerate(ilist):
+            row = neigh[first[r]:first[r + 1]]
+            want = plan.neigh[plan.first[i]:plan.first[i + 1]]
+            assert np.array_equal(row, want)
+            has_ghost = bool((row >= plan.nlocal).any())
+            if r < na or r >= na + nb:
+                assert not has_ghost          # the overlapped ranges never read a ghost position
