@@ -9,9 +9,9 @@ A "step" is one force call on positions already resident in HBM: zero the force 
 (N > 1: forward halo of ghost positions), the fused MTP kernel with global energy and virial
 tallies, (N > 1: reverse halo of ghost forces).  N > 1 shards the SAME 65,536 atoms by
 spatial domain decomposition (strong scaling, as BASELINE.json's metric asks); the halo is
-the library's own (mtp_halo_force_step: device pack / unpack + one grouped RCCL send/recv
-per direction on its own stream; the interior atoms run on a side stream beside both
-exchanges and the boundary atoms) -- no torch collective in the timed loop.
+the library's own (mtp_halo_*: device pack / unpack + one grouped RCCL send/recv per
+direction on its own stream) and the owned atoms run as interior | boundary | interior row
+ranges so both exchanges overlap force work -- no torch collective in the timed loop.
 Rank 0 prints one JSON line; `roofline` prices the dominant kernel against its algorithmic
 HBM bytes and `cpu_baseline` times the CPU oracle on this box's host
 cores in the same run.
@@ -72,7 +72,7 @@ def main():
     import torch
     import torch.distributed as dist
     from lammps_mtp_kokkos_amd import capi, mtpgen
-    from lammps_mtp_kokkos_amd.domain import HaloExchange, decompose, interior_first_order
+    from lammps_mtp_kokkos_amd.domain import HaloExchange, decompose, overlap_order
 
     # BASELINE.json configs other than the headline one (the default is untouched by these)
     cells3 = (args.cells,) * 3
@@ -129,10 +129,10 @@ def main():
     decomposed = world > 1 or self_halo
     use_rows = decomposed and os.environ.get("MTP_BENCH_OVERLAP", "1") != "0"
     if use_rows:
-        ilist_np, first_np, neigh_np, (n_a, n_b) = interior_first_order(plan)
+        ilist_np, first_np, neigh_np, (n_a, n_b, n_c) = overlap_order(plan)
     else:
         ilist_np, first_np, neigh_np = plan.ilist, plan.first, plan.neigh
-        n_a, n_b = 0, plan.nlocal
+        n_a, n_b, n_c = 0, plan.nlocal, 0
     il = torch.from_numpy(ilist_np).to(dev)
     fi = torch.from_numpy(first_np).to(dev)
     ne = torch.from_numpy(neigh_np).to(dev)
@@ -180,7 +180,7 @@ def main():
 
     def step():
         if decomposed and halo_kind == "native":     # zero f, forward halo || rows A, rows B, reverse halo || rows C, fold
-            halo.force_step(ctx, (n_a, n_b), x, ty, f, ev_t=ev, **kw)
+            halo.force_step(ctx, (n_a, n_b, n_c), x, ty, f, ev_t=ev, **kw)
             return
         capi.zero_async(f, stream)
         if world == 1:
@@ -190,7 +190,7 @@ def main():
             if n_a:
                 ctx.compute_device_rows(0, n_a, False, x, ty, f, **kw)
             halo.forward_end(h)
-            ctx.compute_device_rows(n_a, n_b, True, x, ty, f, ev_t=ev, **kw)
+            ctx.compute_device_rows(n_a, n_b + n_c, True, x, ty, f, ev_t=ev, **kw)
             halo.reverse(f)
 
     def fence():
@@ -374,7 +374,7 @@ def main():
                            "library halo: grouped RCCL send/recv per direction (communicator of %d ranks, RCCL %d)"
                            % (halo_info["nranks"], halo_info["rccl_version"]) if halo_info else "torch all-to-all halo (%s)%s" % (
                                backend, "; " + halo_note if halo_note else ""),
-                           ", rows interior|boundary = %d|%d: interior rows run beside both exchanges" % (n_a, n_b) if use_rows else ""))
+                           ", rows interior|boundary|interior = %d|%d|%d overlap both exchanges" % (n_a, n_b, n_c) if use_rows else ""))
                        if decomposed else "single GPU",
                        "atoms_rank0": plan.nlocal, "ghosts_rank0": plan.nghost, "list_entries_rank0": int(plan.first[-1]),
                        "in_cutoff_pairs_rank0": jc_total, "launch": info,

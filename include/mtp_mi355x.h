@@ -147,12 +147,10 @@ int mtp_compute_device(mtp_context *ctx, void *stream, const double *d_x, const 
  * domain-decomposed step splits its owned atoms into those whose list holds no ghost and the rest, so that the
  * former are computed while the ghost positions are still in flight (what LAMMPS-KOKKOS does with its
  * interior / boundary kernels; reference anchor for the semantics: pair_mtp.cpp:252-254, 315).  Energy and virial
- * keep accumulating in the context's tally slots over the launches of a step; the launch with MTP_ROWS_FINISH in
- * `flags` folds them into d_ev (the others may pass d_ev = NULL; row_count = 0 with the flag just folds).  Grades / candidate vectors of the rows are produced
+ * keep accumulating in the context's tally slots over the launches of a step; the launch with finish_tallies != 0
+ * folds them into d_ev (the others may pass d_ev = NULL).  Grades / candidate vectors of the rows are produced
  * per launch. */
-#define MTP_ROWS_FINISH 1    /* fold the energy / virial tallies of the step into d_ev after this launch */
-#define MTP_ROWS_FULL_GRID 2 /* one wavefront per atom instead of the persistent grid: for launches that share the GPU */
-int mtp_compute_device_rows(mtp_context *ctx, void *stream, int row_begin, int row_count, int flags,
+int mtp_compute_device_rows(mtp_context *ctx, void *stream, int row_begin, int row_count, int finish_tallies,
                             const double *d_x, const int *d_type, int eflag, int vflag, int grade_flag,
                             double *d_f, double *d_eatom, double *d_vatom, double *d_ev, double *d_grades,
                             double *d_max_grade, double *d_coeff_ders);
@@ -175,7 +173,6 @@ int mtp_zero_async(void *stream, double *d_p, long long n);
  * order in either mode.  Default off: native fp64 HBM atomics, whose sums depend on arrival order in the last bits
  * (as the reference's own Kokkos atomics do, KOKKOS/pair_mtp_kokkos.cpp:602-605). */
 int mtp_context_set_deterministic(mtp_context *ctx, int enable);
-int mtp_context_get_deterministic(const mtp_context *ctx);
 /* register build the planner chose (2 or 3 wavefronts per SIMD) and whether the per-atom LDS image uses the
  * "rebuild" layout (radial tables built twice, moments overlaying them) */
 int mtp_context_plan_info(const mtp_context *ctx, int32_t *waves_per_simd, int32_t *rebuild_tables);
@@ -225,13 +222,10 @@ int mtp_halo_reverse_begin(mtp_halo *halo, void *stream, const double *d_f /*[na
 int mtp_halo_reverse_end(mtp_halo *halo, void *stream, double *d_f);
 int mtp_halo_reverse(mtp_halo *halo, void *stream, double *d_f);
 /* One domain-decomposed force call with both exchanges overlapped.  The installed list must be ordered interior |
- * boundary (rows_interior + rows_boundary = inum; interior = no ghost in the atom's list).  Zero d_f and pack on
- * `stream`; forward exchange on the halo's stream; the interior rows on a low-priority side stream, concurrently;
- * the boundary rows on `stream` once the ghosts have landed; reverse exchange as soon as those are done; fold and
- * energy / virial totals (into d_ev) when everything has finished.  Both force launches use one wavefront per atom
- * (MTP_ROWS_FULL_GRID) so they share the GPU at workgroup granularity.  Asynchronous; `stream` ends up ordered
- * behind all of it. */
-int mtp_halo_force_step(mtp_halo *halo, mtp_context *ctx, void *stream, int rows_interior, int rows_boundary,
+ * boundary | interior (rows_a + rows_b + rows_c = inum; interior = no ghost in the atom's list): zero d_f, forward
+ * halo || rows [0, rows_a), boundary rows, reverse halo || the last rows_c rows, fold; tallies folded into d_ev by
+ * the last force launch.  Everything is asynchronous on `stream` and the halo's stream. */
+int mtp_halo_force_step(mtp_halo *halo, mtp_context *ctx, void *stream, int rows_a, int rows_b, int rows_c,
                         double *d_x, const int *d_type, int eflag, int vflag, int grade_flag, double *d_f,
                         double *d_eatom, double *d_vatom, double *d_ev, double *d_grades, double *d_max_grade,
                         double *d_coeff_ders);

@@ -30,7 +30,7 @@ EXPORTS = [
     "mtp_halo_reverse_end", "mtp_halo_reverse", "mtp_halo_allreduce", "mtp_halo_force_step",
     "mtp_ghosts_create", "mtp_ghosts_destroy", "mtp_ghosts_last_error", "mtp_ghosts_build", "mtp_ghosts_forward",
     "mtp_ghosts_reverse", "mtp_ghosts_types", "mtp_nve_initial", "mtp_nve_final", "mtp_nve_monitor",
-    "mtp_context_set_deterministic", "mtp_context_get_deterministic", "mtp_zero_async",
+    "mtp_context_set_deterministic", "mtp_zero_async",
 ]
 HALO_ID_BYTES = 128
 REDUCE_SUM, REDUCE_MAX = 0, 1
@@ -261,12 +261,10 @@ class Context:
                                              _ptr(ev_t), _ptr(grades_t), _ptr(maxg_t), _ptr(coeff_t)))
 
     def compute_device_rows(self, row_begin, row_count, finish, x_t, type_t, f_t, eflag=0, vflag=0, grade=False,
-                            eatom_t=None, vatom_t=None, ev_t=None, grades_t=None, maxg_t=None, coeff_t=None, stream=None,
-                            full_grid=False):
+                            eatom_t=None, vatom_t=None, ev_t=None, grades_t=None, maxg_t=None, coeff_t=None, stream=None):
         """Rows [row_begin, row_begin + row_count) of the installed list; `finish` folds the energy / virial tallies."""
         st = C.c_void_p(stream) if stream else None
-        self._check(lib().mtp_compute_device_rows(self.h, st, int(row_begin), int(row_count),
-                                                  (1 if finish else 0) | (2 if full_grid else 0),
+        self._check(lib().mtp_compute_device_rows(self.h, st, int(row_begin), int(row_count), int(bool(finish)),
                                                   _ptr(x_t), _ptr(type_t), int(eflag), int(vflag), int(bool(grade)),
                                                   _ptr(f_t), _ptr(eatom_t), _ptr(vatom_t), _ptr(ev_t),
                                                   _ptr(grades_t), _ptr(maxg_t), _ptr(coeff_t)))
@@ -370,10 +368,9 @@ class Halo:
 
     def force_step(self, ctx, rows, x_t, type_t, f_t, eflag=0, vflag=0, grade=False, eatom_t=None, vatom_t=None, ev_t=None,
                    grades_t=None, maxg_t=None, coeff_t=None, stream=None):
-        """rows = (interior, boundary) of the installed list (interior rows first): zero f, forward halo || interior
-        rows (side stream), boundary rows, reverse halo, fold, tallies -- one C call"""
-        ni, nb = rows
-        rc = lib().mtp_halo_force_step(self.h, ctx.h, self._st(stream), int(ni), int(nb), _ptr(x_t), _ptr(type_t),
+        """zero f, forward halo || interior rows, boundary rows, reverse halo || interior rows, fold (one C call)"""
+        na, nb, nc = rows
+        rc = lib().mtp_halo_force_step(self.h, ctx.h, self._st(stream), int(na), int(nb), int(nc), _ptr(x_t), _ptr(type_t),
                                        int(eflag), int(vflag), int(bool(grade)), _ptr(f_t), _ptr(eatom_t), _ptr(vatom_t),
                                        _ptr(ev_t), _ptr(grades_t), _ptr(maxg_t), _ptr(coeff_t))
         if rc:

@@ -745,13 +745,12 @@ int mtp_copy_neighbors_to_host(mtp_context *c, int *first, int *neigh)
   return MTP_OK;
 }
 
-int mtp_compute_device_rows(mtp_context *c, void *stream, int row_begin, int row_count, int flags,
+int mtp_compute_device_rows(mtp_context *c, void *stream, int row_begin, int row_count, int finish_tallies,
                             const double *d_x, const int *d_type, int eflag, int vflag, int grade_flag, double *d_f,
                             double *d_eatom, double *d_vatom, double *d_ev, double *d_grades, double *d_max_grade,
                             double *d_coeff_ders)
 {
   if (!c) return MTP_ERR_ARG;
-  const bool finish_tallies = (flags & MTP_ROWS_FINISH) != 0, full_grid = (flags & MTP_ROWS_FULL_GRID) != 0;
   if (row_begin < 0 || row_count < 0 || (c->have_list && row_begin + row_count > c->inum)) {
     c->last_error = "row range outside the neighbour list";
     return MTP_ERR_ARG;
@@ -818,14 +817,8 @@ int mtp_compute_device_rows(mtp_context *c, void *stream, int row_begin, int row
   const size_t lds_launch = blob_launch + (size_t) wpb_launch * L.wave_doubles * 8;
   auto grid_for = [&](const mtp_context::LaunchPlan &lp_, int wpb_) {
     int g = (row_count + wpb_ - 1) / wpb_;
-    if (full_grid) {
-      // one atom per wavefront, as many workgroups as that takes: launches that share the GPU with another launch
-      // (interior rows beside boundary rows, two streams) interleave at workgroup granularity and leave no tail
-    } else if (wpb_ == lp_.wpb) {
-      g = std::min(lp_.grid, g);
-    } else {
-      g = std::min(g, c->num_cus * (int) std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds_launch, 1)));
-    }
+    if (wpb_ == lp_.wpb) g = std::min(lp_.grid, g);
+    else g = std::min(g, c->num_cus * (int) std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds_launch, 1)));
     if (g >= 8) g = (g + 7) / 8 * 8;   // whole rounds of the 8 XCDs for the XCD-aware atom map
     return std::max(1, g);
   };
@@ -906,7 +899,7 @@ int mtp_compute_device(mtp_context *c, void *stream, const double *d_x, const in
                        double *d_grades, double *d_max_grade, double *d_coeff_ders)
 {
   if (!c) return MTP_ERR_ARG;
-  return mtp_compute_device_rows(c, stream, 0, c->inum, MTP_ROWS_FINISH, d_x, d_type, eflag, vflag, grade_flag, d_f, d_eatom, d_vatom,
+  return mtp_compute_device_rows(c, stream, 0, c->inum, 1, d_x, d_type, eflag, vflag, grade_flag, d_f, d_eatom, d_vatom,
                                  d_ev, d_grades, d_max_grade, d_coeff_ders);
 }
 
@@ -1028,8 +1021,6 @@ int mtp_debug_read_stamps(mtp_context *c, unsigned long long *out16)
   (void) hipMemset(c->d_stamps.ptr, 0, 16 * sizeof(unsigned long long));
   return MTP_OK;
 }
-
-int mtp_context_get_deterministic(const mtp_context *c) { return c && c->deterministic ? 1 : 0; }
 
 int mtp_zero_async(void *stream, double *d_p, long long n)
 {

@@ -71,9 +71,9 @@ void copy_err(const std::string &s, char *err, int errlen)
 struct mtp_halo {
   int device = 0, nranks = 1, rank = 0;
   ncclComm_t comm = nullptr;
-  hipStream_t comm_stream = nullptr, side_stream = nullptr;
+  hipStream_t comm_stream = nullptr;
   hipEvent_t ev_fwd_ready = nullptr, ev_fwd_done = nullptr, ev_rev_ready = nullptr, ev_rev_done = nullptr,
-             ev_red_ready = nullptr, ev_red_done = nullptr, ev_side_ready = nullptr, ev_side_done = nullptr;
+             ev_red_ready = nullptr, ev_red_done = nullptr;
   int nlocal = 0, nghost = 0, nsend = 0;
   int *d_send_idx = nullptr;
   double *d_send_shift = nullptr, *d_sendbuf = nullptr, *d_frecv = nullptr;
@@ -84,11 +84,9 @@ struct mtp_halo {
     (void) hipSetDevice(device);
     if (comm_stream) (void) hipStreamSynchronize(comm_stream);
     if (comm) (void) ncclCommDestroy(comm);
-    if (side_stream) (void) hipStreamSynchronize(side_stream);
-    for (hipEvent_t e : {ev_fwd_ready, ev_fwd_done, ev_rev_ready, ev_rev_done, ev_red_ready, ev_red_done, ev_side_ready, ev_side_done})
+    for (hipEvent_t e : {ev_fwd_ready, ev_fwd_done, ev_rev_ready, ev_rev_done, ev_red_ready, ev_red_done})
       if (e) (void) hipEventDestroy(e);
     if (comm_stream) (void) hipStreamDestroy(comm_stream);
-    if (side_stream) (void) hipStreamDestroy(side_stream);
     for (void *p : {(void *) d_send_idx, (void *) d_send_shift, (void *) d_sendbuf, (void *) d_frecv})
       if (p) (void) hipFree(p);
   }
@@ -155,14 +153,9 @@ int mtp_halo_create(int device_id, int nranks, int rank, const void *unique_id, 
       h->send_off[q + 1] = h->send_off[q] + send_counts[q];
       h->recv_off[q + 1] = h->recv_off[q] + recv_counts[q];
     }
-    {   // exchanges first, interior rows last: stream priorities (numerically lower = higher priority)
-      int prio_lo = 0, prio_hi = 0;
-      HIP_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-      HIP_OK(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, prio_hi));
-      HIP_OK(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_lo));
-    }
+    HIP_OK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
     for (hipEvent_t *e : {&h->ev_fwd_ready, &h->ev_fwd_done, &h->ev_rev_ready, &h->ev_rev_done, &h->ev_red_ready,
-                          &h->ev_red_done, &h->ev_side_ready, &h->ev_side_done})
+                          &h->ev_red_done})
       HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     const size_t n = (size_t) std::max<long long>(nsend, 1);
     HIP_OK(hipMalloc(reinterpret_cast<void **>(&h->d_send_idx), n * sizeof(int)));
@@ -303,48 +296,31 @@ int mtp_halo_reverse(mtp_halo *h, void *stream, double *d_f)
   return rc != MTP_OK ? rc : mtp_halo_reverse_end(h, stream, d_f);
 }
 
-// One domain-decomposed force call with both exchanges overlapped.  The rows of the installed list are ordered
-// interior | boundary (interior = no ghost in the atom's list):
-//   caller's stream   zero f, pack ................ wait(forward) boundary rows ........... wait(reverse, side) fold, tallies
-//   halo's stream            forward exchange ............................ reverse exchange
-//   side stream (low priority)  interior rows, one atom per wavefront ...............................
-// The two force launches share the GPU at workgroup granularity (neither is a persistent grid), the boundary rows on
-// the higher-priority stream, so the reverse exchange starts as early as possible and the interior rows fill whatever
-// the boundary launch and the exchanges leave idle -- no launch waits for another launch's last round of wavefronts.
-int mtp_halo_force_step(mtp_halo *h, mtp_context *ctx, void *stream, int rows_interior, int rows_boundary, double *d_x,
+// One domain-decomposed force call with both exchanges overlapped (rows of the installed list ordered interior A |
+// boundary | interior C): zero f; forward halo || rows A; boundary rows; reverse halo || rows C; fold.  One entry
+// point instead of eight, so a driver's per-call overhead is paid once per step.
+int mtp_halo_force_step(mtp_halo *h, mtp_context *ctx, void *stream, int rows_a, int rows_b, int rows_c, double *d_x,
                         const int *d_type, int eflag, int vflag, int grade_flag, double *d_f, double *d_eatom,
                         double *d_vatom, double *d_ev, double *d_grades, double *d_max_grade, double *d_coeff_ders)
 {
-  if (!h || !ctx || !d_x || !d_f || rows_interior < 0 || rows_boundary < 0) return MTP_ERR_ARG;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  int rc = MTP_OK;
-  try {
-    HIP_OK(hipSetDevice(h->device));
-    if (mtp_zero_async(stream, d_f, 3ll * (h->nlocal + h->nghost)) != MTP_OK) throw HaloFail{"zeroing f failed"};
-    HIP_OK(hipEventRecord(h->ev_side_ready, st));
-    rc = mtp_halo_forward_begin(h, stream, d_x);
-    // (deterministic mode keeps one launch at a time: its fixed-point accumulators are converted after every launch)
-    hipStream_t side = mtp_context_get_deterministic(ctx) ? st : h->side_stream;
-    if (rc == MTP_OK && rows_interior > 0) {
-      if (side != st) HIP_OK(hipStreamWaitEvent(side, h->ev_side_ready, 0));
-      rc = mtp_compute_device_rows(ctx, side, 0, rows_interior, MTP_ROWS_FULL_GRID, d_x, d_type, eflag, vflag,
-                                   grade_flag, d_f, d_eatom, d_vatom, d_ev, d_grades, d_max_grade, d_coeff_ders);
-      if (side != st) HIP_OK(hipEventRecord(h->ev_side_done, side));
-    }
-    if (rc == MTP_OK) rc = mtp_halo_forward_end(h, stream);
-    if (rc == MTP_OK)
-      rc = mtp_compute_device_rows(ctx, stream, rows_interior, rows_boundary, MTP_ROWS_FULL_GRID, d_x, d_type, eflag, vflag,
-                                   grade_flag, d_f, d_eatom, d_vatom, d_ev, d_grades, d_max_grade, d_coeff_ders);
-    if (rc == MTP_OK) rc = mtp_halo_reverse_begin(h, stream, d_f);
-    if (rc == MTP_OK) rc = mtp_halo_reverse_end(h, stream, d_f);   // (atomic adds, like the interior launch's own)
-    if (rc == MTP_OK && rows_interior > 0 && side != st) HIP_OK(hipStreamWaitEvent(st, h->ev_side_done, 0));
-    if (rc == MTP_OK)   // both launches have finished on `stream`'s timeline: fold the energy / virial tallies
-      rc = mtp_compute_device_rows(ctx, stream, 0, 0, MTP_ROWS_FINISH, d_x, d_type, eflag, vflag, 0, d_f, nullptr, nullptr, d_ev,
-                                   nullptr, nullptr, nullptr);
-  } catch (const HaloFail &f) {
-    h->last_error = f.what;
+  if (!h || !ctx || !d_x || !d_f || rows_a < 0 || rows_b < 0 || rows_c < 0) return MTP_ERR_ARG;
+  if (mtp_zero_async(stream, d_f, 3ll * (h->nlocal + h->nghost)) != MTP_OK) {
+    h->last_error = "zeroing f failed";
     return MTP_ERR_DEVICE;
   }
+  int rc = mtp_halo_forward_begin(h, stream, d_x);
+  if (rc == MTP_OK && rows_a > 0)
+    rc = mtp_compute_device_rows(ctx, stream, 0, rows_a, 0, d_x, d_type, eflag, vflag, grade_flag, d_f, d_eatom, d_vatom,
+                                 d_ev, d_grades, d_max_grade, d_coeff_ders);
+  if (rc == MTP_OK) rc = mtp_halo_forward_end(h, stream);
+  if (rc == MTP_OK)
+    rc = mtp_compute_device_rows(ctx, stream, rows_a, rows_b, rows_c == 0, d_x, d_type, eflag, vflag, grade_flag, d_f,
+                                 d_eatom, d_vatom, d_ev, d_grades, d_max_grade, d_coeff_ders);
+  if (rc == MTP_OK) rc = mtp_halo_reverse_begin(h, stream, d_f);
+  if (rc == MTP_OK && rows_c > 0)
+    rc = mtp_compute_device_rows(ctx, stream, rows_a + rows_b, rows_c, 1, d_x, d_type, eflag, vflag, grade_flag, d_f,
+                                 d_eatom, d_vatom, d_ev, d_grades, d_max_grade, d_coeff_ders);
+  if (rc == MTP_OK) rc = mtp_halo_reverse_end(h, stream, d_f);
   return rc;
 }
 

@@ -241,12 +241,3 @@ def overlap_order(plan: HaloPlan, round_atoms=3072):
                             interior[len(interior) - nc:]]).astype(np.int64)
     ilist, first, neigh = sub_list(plan, order)
     return ilist, first, neigh, (na, len(order) - na - nc, nc)
-
-
-def interior_first_order(plan: HaloPlan):
-    """Neighbour list of the rank with the interior atoms (no ghost in their list) first and the boundary atoms
-    behind them: the row order mtp_halo_force_step takes.  Returns (ilist, first, neigh, (n_interior, n_boundary))."""
-    interior, boundary = split_interior(plan)
-    order = np.concatenate([interior, boundary]).astype(np.int64)
-    ilist, first, neigh = sub_list(plan, order)
-    return ilist, first, neigh, (len(interior), len(boundary))
