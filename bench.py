@@ -243,7 +243,7 @@ def main():
     # rocprofv3 PMC counters of the dominant kernel (scripts/gpu_pmc.sh -> profiles/r02_pmc_counters.json): only quoted when
     # they were collected from THIS build of the kernels (source hash) on this workload; per launch, like `achieved`
     traffic, pmc_block = None, None
-    cpath = os.path.join(ROOT, "profiles", "r02_pmc_counters.json")
+    cpath = os.path.join(ROOT, "profiles", "r02_pmc_counters%s.json" % ("" if args.workload == "w16" else "_" + args.workload))
     if os.path.exists(cpath) and world == 1:
         try:
             pc = json.load(open(cpath))
@@ -254,7 +254,7 @@ def main():
                 cyc = kernel_ms * 1e-3 * 2.4e9      # at the 2.4 GHz peak clock: busy fractions are lower bounds
                 ncu = 256
                 pmc_block = {
-                    "source": "profiles/r02_pmc_counters.json (same kernel sources: %s)" % pc["source_hash"][:12],
+                    "source": "profiles/%s (same kernel sources: %s)" % (os.path.basename(cpath), pc["source_hash"][:12]),
                     "lds_busy": cn["SQ_LDS_IDX_ACTIVE"] / ncu / cyc,                    # LDS pipe cycles / kernel cycles, per CU
                     "lds_bank_conflict_share": cn["SQ_LDS_BANK_CONFLICT"] / max(cn["SQ_LDS_IDX_ACTIVE"], 1.0),
                     "valu_busy": cn["SQ_INSTS_VALU"] * 4.0 / (4 * ncu) / cyc,           # 4 issue cycles per fp64 wave instruction, 4 SIMDs per CU

@@ -28,19 +28,28 @@ sys.path.insert(0, ".")
 from lammps_mtp_kokkos_amd import capi
 args = "$ARGS".split()
 workload = args[args.index("--workload") + 1] if "--workload" in args else "w16"
-tot = {}
+tot, others = {}, collections.defaultdict(dict)
 for name in ["sq1","sq2","sq3","tcc1","tcc2","tcc3"]:
     files = glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True)
     acc = collections.defaultdict(list)
     for f in files:
         for row in csv.DictReader(open(f)):
-            if "mtp_wave_kernel" in row.get("Kernel_Name",""):
-                acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-    for k,v in acc.items():
-        print("%s %-28s mean per launch %.6g  (n=%d)" % (name, k, sum(v)/len(v), len(v)))
-        tot[k] = sum(v)/len(v)
+            kn = row.get("Kernel_Name","")
+            if "mtp_wave_kernel" in kn:
+                acc[("", row["Counter_Name"])].append(float(row["Counter_Value"]))
+            else:
+                for short in ("mtp_grade_kernel_lds", "mtp_grade_kernel", "mtp_cvec_kernel", "mtp_ev_finish"):
+                    if short in kn:
+                        acc[(short, row["Counter_Name"])].append(float(row["Counter_Value"]))
+                        break
+    for (kn, k), v in acc.items():
+        if kn == "":
+            print("%s %-28s mean per launch %.6g  (n=%d)" % (name, k, sum(v)/len(v), len(v)))
+            tot[k] = sum(v)/len(v)
+        else:
+            others[kn][k] = sum(v)/len(v)
 out = {"source_hash": capi.kernel_source_hash(), "workload": workload, "cells": 32, "kernel": "mtp_wave_kernel",
-       "counters": tot,
+       "counters": tot, "other_kernels": others,
        "note": "rocprofv3 --kernel-trace --pmc, separate passes, mean per launch of mtp_wave_kernel under bench.py. "
                "FETCH_SIZE / WRITE_SIZE in KB as reported: FETCH_SIZE is taken as is (the guide's x2 correction is calibrated "
                "for 16 B/lane streams, these reads are 4-8 B gathers: uncalibrated), WRITE_SIZE is exact for atomics."}
