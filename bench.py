@@ -43,6 +43,26 @@ def algorithmic_flops_reference(sizes, jc_total, nlocal):
     return jc_total * (9 + 8 * R + 4 * P + 4 * Mu * R + 34 * B) + nlocal * (9 * T + 2 * S)
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota where one is set (a GPU box
+    hands each lease a share of its host cores)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(round(q / per))))
+        except Exception:
+            pass
+    return n
+
+
 def info_launch_waves(ctx):
     i = ctx.launch_info()
     return i["waves_per_block"] * max(1, i["grid_blocks"] // 256)
@@ -251,15 +271,18 @@ def main():
                     and pc.get("cells", 32) == args.cells:
                 cn = pc["counters"]
                 traffic = pc.get("hbm_bytes_per_launch")
-                cyc = kernel_ms * 1e-3 * 2.4e9      # at the 2.4 GHz peak clock: busy fractions are lower bounds
+                # kernel duration in shader cycles from the same counters: the wavefronts of the persistent grid live for the
+                # whole launch, SQ_WAVE_CYCLES counts quad-cycles (MI355X_MICROARCH.md)
                 ncu = 256
+                cyc = cn["SQ_WAVE_CYCLES"] * 4.0 / cn["SQ_WAVES"]
                 pmc_block = {
                     "source": "profiles/%s (same kernel sources: %s)" % (os.path.basename(cpath), pc["source_hash"][:12]),
-                    "lds_busy": cn["SQ_LDS_IDX_ACTIVE"] / ncu / cyc,                    # LDS pipe cycles / kernel cycles, per CU
+                    "lds_busy": cn["SQ_LDS_IDX_ACTIVE"] / ncu / cyc,                       # LDS pipe cycles / kernel cycles, per CU
                     "lds_bank_conflict_share": cn["SQ_LDS_BANK_CONFLICT"] / max(cn["SQ_LDS_IDX_ACTIVE"], 1.0),
-                    "valu_busy": cn["SQ_INSTS_VALU"] * 4.0 / (4 * ncu) / cyc,           # 4 issue cycles per fp64 wave instruction, 4 SIMDs per CU
+                    "valu_busy": cn["SQ_ACTIVE_INST_VALU"] * 4.0 / (4 * ncu) / cyc,         # quad-cycles of VALU issue per SIMD
+                    "kernel_cycles": cyc, "clock_ghz_under_profiler": cyc / (kernel_ms * 1e-3) / 1e9,
                     "lds_wave_instructions": cn["SQ_INSTS_LDS"], "valu_wave_instructions": cn["SQ_INSTS_VALU"],
-                    "waves_per_cu": info_launch_waves(ctx),
+                    "waves_per_cu": cn["SQ_WAVES"] / ncu,
                 }
         except Exception:
             traffic, pmc_block = None, None
@@ -286,7 +309,7 @@ def main():
                "sample": "%d passes over the first %d of the %d atoms (same lattice, potential, list, flags), "
                          "serial C oracle, %.1f s" % (passes, nsub, natoms, tcpu),
                "host_cpus": os.cpu_count()}
-        nthr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        nthr = usable_cpus()
         if nthr > 1 and not grade:
             mp_, tmt = 0, 0.0
             while tmt < args.cpu_seconds / 2 and mp_ < 200:
