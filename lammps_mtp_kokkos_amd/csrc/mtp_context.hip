@@ -67,7 +67,7 @@ struct mtp_context {
   bool xcd_map = true;   // MTP_XCD_MAP=0 (tuning override) turns the XCD-aware atom map off
   // potential tables
   DevBuf<double> d_species;
-  DevBuf<MtpRow8> d_rows;
+  DevBuf<MtpRow8> d_rows, d_prog_fwd, d_prog_bwd;
   DevBuf<unsigned char> d_blob;
   DevBuf<int32_t> d_seed_idx, d_map;
   DevBuf<double> d_seed_val, d_lin;
@@ -424,6 +424,17 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
       rows8[k].hi = (uint32_t) r.a3 | (((uint32_t) r.mult & 0xffffu) << 16);
     }
     c->d_rows.upload(rows8.data(), rows8.size(), st);
+    auto pack_prog = [&](const std::vector<MtpRow> &prog, DevBuf<MtpRow8> &buf) {
+      std::vector<MtpRow8> p8(prog.size());
+      for (size_t k = 0; k < prog.size(); k++) {
+        const MtpRow &r = prog[k];
+        p8[k].lo = (uint32_t) r.a0 | ((uint32_t) r.a1 << 16);
+        p8[k].hi = (uint32_t) r.a3 | (((uint32_t) r.mult & 0xffffu) << 16);
+      }
+      buf.upload(p8.data(), p8.size(), st);
+    };
+    pack_prog(pot->prog_fwd, c->d_prog_fwd);
+    pack_prog(pot->prog_bwd, c->d_prog_bwd);
     // table blob copied into LDS by every workgroup
     MtpDevParams &bb = c->base;
     // The packed rows are the LAST piece of the blob: a launch plan copies them into LDS (blob_bytes_rows) or leaves
@@ -437,6 +448,8 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
       return (int) off;
     };
     bb.off_level = put(pot->level_offset.data(), pot->level_offset.size() * sizeof(int32_t));
+    bb.off_seg_fwd = put(pot->seg_fwd.data(), pot->seg_fwd.size() * sizeof(int32_t));
+    bb.off_seg_bwd = put(pot->seg_bwd.data(), pot->seg_bwd.size() * sizeof(int32_t));
     std::vector<int32_t> slot_pad((size_t) pot->radial_func_count * MTP_PSTRIDE, -1);
     for (int mu = 0; mu < pot->radial_func_count; mu++)
       for (int nu = 0; nu < pot->max_alpha_index_basic; nu++)
@@ -529,6 +542,8 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     b.inv_span = 1.0 / (pot->max_cutoff - pot->min_cutoff);
     b.blob = c->d_blob.ptr;
     b.rows = c->d_rows.ptr;
+    b.prog_fwd = c->d_prog_fwd.ptr;
+    b.prog_bwd = c->d_prog_bwd.ptr;
     b.species_coeffs = c->d_species.ptr;
     b.inv_mu = 1.0f / (float) pot->radial_func_count;
     b.ev_slots = c->d_ev_slots.ptr;

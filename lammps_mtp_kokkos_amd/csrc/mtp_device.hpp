@@ -52,6 +52,9 @@ struct MtpDevParams {
   const int *g_map, *g_seed_idx;
   const double *g_lin, *g_seed_val;
   const MtpRow8 *rows;     // [T] by level, in HBM (always valid)
+  // gather programs of the product passes (mtp_potential.hpp): operations in HBM / L2, segment tables in the blob
+  const MtpRow8 *prog_fwd, *prog_bwd;
+  int off_seg_fwd, off_seg_bwd;   // int[nlevels][4] {first block, groups, chunk size, 0}
   const double *species_coeffs;
   // system
   int inum, nall;

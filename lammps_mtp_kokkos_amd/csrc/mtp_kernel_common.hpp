@@ -154,7 +154,7 @@ template <> struct Butterfly<1> {
 
 struct BlockTables {   // views into the workgroup-shared head of LDS
   const MtpRow8 *rows;
-  const int *level, *slot, *seed_idx, *map, *pack, *coef, *smu, *fwd;
+  const int *level, *slot, *seed_idx, *map, *pack, *coef, *smu, *fwd, *seg_fwd, *seg_bwd;
   const double *radial, *seed_val, *lin;
 };
 

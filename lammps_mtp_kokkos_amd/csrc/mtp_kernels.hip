@@ -319,9 +319,13 @@ __device__ __forceinline__ void products_forward(const MtpRow8 *rows, const int 
       for (int u = 0; u < U; u++) rw[u] = rp[64 * min(it + u, nit - 1)];   // uniform clamp: the tail re-reads the last block
 #pragma unroll
       for (int u = 0; u < U; u++) v[u] = M[rw[u].lo & 0xffffu] * M[rw[u].lo >> 16];
+#ifdef MTP_EXP_GATHER_EMU   // timing experiment (wrong results): one add per four rows, as a target-sorted gather would issue
+      if (it < nit) lds_add(&M[rw[0].hi & 0xffffu], (double) ((int) rw[0].hi >> 16) * (v[0] + v[1] + v[2] + v[3]));
+#else
 #pragma unroll
       for (int u = 0; u < U; u++)
         if (it + u < nit) lds_add(&M[rw[u].hi & 0xffffu], (double) ((int) rw[u].hi >> 16) * v[u]);   // uniform branch
+#endif
     }
     wave_fence();
   }
@@ -347,13 +351,95 @@ __device__ __forceinline__ void products_backward(const MtpRow8 *rows, const int
         m0[u] = M[rw[u].lo & 0xffffu];
         m1[u] = M[rw[u].lo >> 16];
       }
+#ifdef MTP_EXP_GATHER_EMU   // timing experiment (wrong results): four reads per row, two adds per four rows
+      {
+        double x4 = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; u++) x4 += D[rw[u].lo & 0xffffu];
+        if (it < nit) {
+          lds_add(&D[rw[0].lo >> 16], d3[0] * m0[0] + d3[1] * m0[1] + x4);
+          lds_add(&D[rw[0].lo & 0xffffu], d3[2] * m1[2] + d3[3] * m1[3]);
+        }
+      }
+#else
 #pragma unroll
       for (int u = 0; u < U; u++)
         if (it + u < nit) {
           lds_add(&D[rw[u].lo >> 16], d3[u] * m0[u]);
           lds_add(&D[rw[u].lo & 0xffffu], d3[u] * m1[u]);
         }
+#endif
     }
+    wave_fence();
+  }
+}
+
+// Phase 4, gather form (round 2).  A level of a pass is a list of chunks; lane l of a group of 64 lanes runs one chunk:
+// acc = sum_u mult_u X[o0_u] Y[o1_u] over its CS operations, then ONE atomic add T[tgt] += acc.  Forward: X = Y = T =
+// moments (rows of one target); reverse: X = adjoints, Y = moments, T = adjoints (the terms of one destination), so a
+// reverse level issues one ds_add_f64 per CS terms instead of two per row.  Operations (8 bytes, lane-contiguous) come
+// from HBM / L2; those of the next trip are requested before the current trip's operands are read.
+template <int CS>
+__device__ __forceinline__ void gather_groups(const MtpRow8 *rp, int ngroups, const double *X, const double *Y, double *T)
+{
+  constexpr int U = CS >= 4 ? 4 : CS;        // operations of one chunk in flight
+  constexpr int G = CS >= 4 ? 1 : 4 / CS;    // chunks in flight
+  constexpr int PARTS = CS / U;              // trips per chunk (CS = 8: two)
+  const int ntrip = ((ngroups + G - 1) / G) * PARTS;
+  MtpRow8 nxt[G][U];
+  auto fetch = [&](int trip, MtpRow8 (&dst)[G][U]) {
+    const int g0 = (trip / PARTS) * G, part = trip % PARTS;
+#pragma unroll
+    for (int j = 0; j < G; j++)
+#pragma unroll
+      for (int u = 0; u < U; u++) dst[j][u] = rp[64 * (min(g0 + j, ngroups - 1) * CS + part * U + u)];
+  };
+  fetch(0, nxt);
+  double acc[G];
+#pragma unroll
+  for (int j = 0; j < G; j++) acc[j] = 0.0;
+  for (int trip = 0; trip < ntrip; trip++) {
+    MtpRow8 cur[G][U];
+#pragma unroll
+    for (int j = 0; j < G; j++)
+#pragma unroll
+      for (int u = 0; u < U; u++) cur[j][u] = nxt[j][u];
+    if (trip + 1 < ntrip) fetch(trip + 1, nxt);   // uniform
+    double xv[G][U], yv[G][U];
+#pragma unroll
+    for (int j = 0; j < G; j++)
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        xv[j][u] = X[cur[j][u].lo & 0xffffu];
+        yv[j][u] = Y[cur[j][u].lo >> 16];
+      }
+#pragma unroll
+    for (int j = 0; j < G; j++)
+#pragma unroll
+      for (int u = 0; u < U; u++) acc[j] = fma((double) ((int) cur[j][u].hi >> 16) * xv[j][u], yv[j][u], acc[j]);
+    if (trip % PARTS == PARTS - 1) {
+      const int g0 = (trip / PARTS) * G;
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        if (g0 + j < ngroups) lds_add(&T[cur[j][0].hi & 0xffffu], acc[j]);   // uniform branch
+        acc[j] = 0.0;
+      }
+    }
+  }
+}
+
+// one pass: the levels in the order the segment table lists them (forward: ascending, reverse: descending)
+__device__ __forceinline__ void gather_pass(const MtpRow8 *prog, const int *seg, int nlevels, const double *X,
+                                            const double *Y, double *T, int lane)
+{
+  for (int l = 0; l < nlevels; l++) {
+    const int first = __builtin_amdgcn_readfirstlane(seg[4 * l]), ngroups = __builtin_amdgcn_readfirstlane(seg[4 * l + 1]);
+    const int cs = __builtin_amdgcn_readfirstlane(seg[4 * l + 2]);
+    const MtpRow8 *rp = prog + (size_t) first * 64 + lane;
+    if (cs == 4) gather_groups<4>(rp, ngroups, X, Y, T);
+    else if (cs == 8) gather_groups<8>(rp, ngroups, X, Y, T);
+    else if (cs == 2) gather_groups<2>(rp, ngroups, X, Y, T);
+    else gather_groups<1>(rp, ngroups, X, Y, T);
     wave_fence();
   }
 }
@@ -459,6 +545,14 @@ template <int KL, int NB, int PITCH, bool GRADE, int DEG, int WPS>
 __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(const MtpDevParams p_arg)
 {
   constexpr int NT = 32;                 // neighbours per tile
+  // Product passes: the wide lane grids (KL = 64: level 18 and up, thousands of times rows that live in HBM / L2 either
+  // way) run the gather programs -- measured at level 20: 2.02 -> 1.93 ms; the narrow grids keep the row-per-lane passes
+  // with the rows in LDS -- at level 16 the gather programs (27 KB, so in L2) were 2.3 % slower (0.523 vs 0.511 ms).
+#ifdef MTP_GATHER_ALL      // diagnostic builds: gather passes for every lane grid
+  constexpr bool GATHER = true;
+#else
+  constexpr bool GATHER = KL == 64;
+#endif
   constexpr int NG = 64 / KL;            // neighbour groups in the wavefront
   constexpr int NPG = NT / NG;           // neighbours per group per tile
   static_assert(NT == 32, "the force phase maps lanes to (32 neighbours) x (2 halves)");
@@ -474,6 +568,8 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
   BlockTables bt;
   bt.rows = reinterpret_cast<const MtpRow8 *>(sh + kp->off_rows);
   bt.level = reinterpret_cast<const int *>(sh + kp->off_level);
+  bt.seg_fwd = reinterpret_cast<const int *>(sh + kp->off_seg_fwd);
+  bt.seg_bwd = reinterpret_cast<const int *>(sh + kp->off_seg_bwd);
   bt.slot = reinterpret_cast<const int *>(sh + kp->off_slot);
   bt.radial = reinterpret_cast<const double *>(sh + kp->off_radial);
   bt.seed_idx = reinterpret_cast<const int *>(sh + kp->off_seed_idx);
@@ -725,8 +821,12 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
 
     // ---- 4a. products, level by level (pair_mtp.cpp:196-201) -----------------------------
 #ifndef MTP_EXP_NOPRODUCTS   // timing / counter experiment only (wrong results)
-    if (rows_lds) products_forward<MTP_PU>(bt.rows, bt.level, kp->nlevels, w.M, lane);
-    else products_forward<MTP_PU>(kp->rows, bt.level, kp->nlevels, w.M, lane);
+    if constexpr (GATHER) {
+      gather_pass(kp->prog_fwd, bt.seg_fwd, kp->nlevels, w.M, w.M, w.M, lane);
+    } else {
+      if (rows_lds) products_forward<MTP_PU>(bt.rows, bt.level, kp->nlevels, w.M, lane);
+      else products_forward<MTP_PU>(kp->rows, bt.level, kp->nlevels, w.M, lane);
+    }
 #endif
     STAMP(4);   // products forward
     KP_FRESH();
@@ -757,8 +857,12 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     STAMP(5);   // energy + seeds
     KP_FRESH();
 #ifndef MTP_EXP_NOPRODUCTS
-    if (rows_lds) products_backward<MTP_PU>(bt.rows, bt.level, kp->nlevels, w.M, w.D, lane);
-    else products_backward<MTP_PU>(kp->rows, bt.level, kp->nlevels, w.M, w.D, lane);
+    if constexpr (GATHER) {
+      gather_pass(kp->prog_bwd, bt.seg_bwd, kp->nlevels, w.D, w.M, w.D, lane);
+    } else {
+      if (rows_lds) products_backward<MTP_PU>(bt.rows, bt.level, kp->nlevels, w.M, w.D, lane);
+      else products_backward<MTP_PU>(kp->rows, bt.level, kp->nlevels, w.M, w.D, lane);
+    }
 #endif
 
     STAMP(6);   // products backward

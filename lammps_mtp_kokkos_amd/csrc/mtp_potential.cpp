@@ -617,6 +617,139 @@ int mtp_potential::finalize(std::string &err)
     }
     for (int32_t &m : seed_idx) m = moment_perm[m];
   }
+  // ---- gather programs of the product passes ---------------------------------------------------------------------
+  // The product passes as the kernel runs them (mtp_kernels.hip, gather_pass): per level a list of *chunks*; a chunk
+  // holds up to cs operations acc += mult * X[o0] * Y[o1] that share one target, lane l of a group of 64 lanes runs one
+  // chunk and ends it with ONE atomic add T[tgt] += acc.  Forward pass (pair_mtp.cpp:196-201): X = Y = T = moments,
+  // chunks = the rows of a target.  Reverse pass (:221-233): X = adjoints, Y = moments, T = adjoints, chunks = the
+  // terms D[a3] mult M[other] of one destination moment -- so the reverse pass needs two atomics per FOUR-TO-EIGHT
+  // rows instead of two per row.  The chunk size cs in {1, 2, 4, 8} is chosen per level and pass by modelled LDS cycles
+  // (2 per read, 15 per atomic add, padding included); chunks are dealt to lanes greedily so that the operands of one
+  // wave instruction spread over the LDS banks (reads: 32 lanes over 32 eight-byte banks, adds: 16 lanes over 16).
+  {
+    const int nlev2 = (int) level_offset.size() - 1;
+    auto build = [&](bool reverse, std::vector<MtpRow> &prog, std::vector<int32_t> &seg) {
+      prog.clear();
+      seg.clear();
+      for (int li = 0; li < nlev2; li++) {
+        const int l = reverse ? nlev2 - 1 - li : li;
+        // operations of the level, keyed by target
+        std::vector<std::vector<MtpRow>> by_tgt((size_t) A);
+        for (int r = level_offset[l]; r < level_offset[l + 1]; r++) {
+          const MtpRow &row = rows_by_level[(size_t) r];
+          if (row.mult == 0) continue;   // neutral padding rows of the old layout
+          if (!reverse) {
+            by_tgt[(size_t) row.a3].push_back(row);
+          } else if (row.a0 == row.a1 && 2 * row.mult <= 32767 && 2 * row.mult >= -32768) {
+            by_tgt[(size_t) row.a0].push_back(MtpRow{row.a3, row.a0, 2 * row.mult, row.a0});   // both terms in one
+          } else {
+            by_tgt[(size_t) row.a1].push_back(MtpRow{row.a3, row.a0, row.mult, row.a1});       // D[a1] += D[a3] mult M[a0]
+            by_tgt[(size_t) row.a0].push_back(MtpRow{row.a3, row.a1, row.mult, row.a0});       // D[a0] += D[a3] mult M[a1]
+          }
+        }
+        // chunk size by modelled LDS cycles
+        int best_cs = 1;
+        long long best_cost = -1;
+        for (int cs : {1, 2, 4, 8}) {
+          long long chunks = 0;
+          for (const auto &v : by_tgt) chunks += ((long long) v.size() + cs - 1) / cs;
+          const long long groups = (chunks + 63) / 64, cost = groups * cs * 6 + groups * 15;
+          if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best_cs = cs;
+          }
+        }
+        const int cs = best_cs;
+        struct Chunk {
+          int tgt;
+          MtpRow op[8];
+        };
+        std::vector<Chunk> chunks;
+        for (int t = 0; t < A; t++) {
+          const auto &v = by_tgt[(size_t) t];
+          for (size_t b = 0; b < v.size(); b += (size_t) cs) {
+            Chunk c;
+            c.tgt = t;
+            for (int u = 0; u < cs; u++) c.op[u] = b + u < v.size() ? v[b + u] : MtpRow{t, t, 0, t};
+            chunks.push_back(c);
+          }
+        }
+        // longest-first would not matter (all chunks are cs long after padding); keep file order, pad to whole groups
+        const int ngroups = (int) ((chunks.size() + 63) / 64);
+        const int first_block = (int) (prog.size() / 64);
+        std::vector<char> used(chunks.size(), 0);
+        size_t scan_from = 0;
+        for (int g = 0; g < ngroups; g++) {
+          int occx[8][2][32], occy[8][2][32], occt[4][16];
+          for (auto &a : occx)
+            for (auto &b : a)
+              for (int &c : b) c = -1;
+          for (auto &a : occy)
+            for (auto &b : a)
+              for (int &c : b) c = -1;
+          for (auto &a : occt)
+            for (int &c : a) c = -1;
+          std::vector<MtpRow> blk((size_t) 64 * cs);
+          for (int lane = 0; lane < 64; lane++) {
+            const int half = lane >> 5, q16 = lane >> 4;
+            int best = -1, best_rot = 0, bcost = 1 << 30, seen = 0;
+            for (size_t k = scan_from; k < chunks.size() && seen < 128; k++) {
+              if (used[k]) continue;
+              seen++;
+              const Chunk &c = chunks[k];
+              const int tcost = 3 * (occt[q16][c.tgt & 15] >= 0);
+              for (int rot = 0; rot < cs; rot++) {
+                int cost = tcost;
+                for (int u = 0; u < cs; u++) {
+                  const MtpRow &o = c.op[(u + rot) % cs];
+                  const int bx = occx[u][half][o.a0 & 31], by = occy[u][half][o.a1 & 31];
+                  cost += (bx >= 0 && bx != o.a0) + (by >= 0 && by != o.a1);
+                }
+                if (cost < bcost) {
+                  bcost = cost;
+                  best = (int) k;
+                  best_rot = rot;
+                }
+                if (cost == 0) break;
+              }
+              if (bcost == 0) break;
+            }
+            Chunk c;
+            if (best >= 0) {
+              c = chunks[(size_t) best];
+              used[(size_t) best] = 1;
+              while (scan_from < chunks.size() && used[scan_from]) scan_from++;
+            } else {   // padding chunk: adds 0.0 to a moment whose add bank is still free in this 16-lane group
+              int t = 0;
+              for (int m = 0; m < A; m++)
+                if (occt[q16][m & 15] < 0) {
+                  t = m;
+                  break;
+                }
+              c.tgt = t;
+              for (int u = 0; u < cs; u++) c.op[u] = MtpRow{t, t, 0, t};
+              best_rot = 0;
+            }
+            occt[q16][c.tgt & 15] = c.tgt;
+            for (int u = 0; u < cs; u++) {
+              MtpRow o = c.op[(u + best_rot) % cs];
+              o.a3 = c.tgt;
+              occx[u][half][o.a0 & 31] = o.a0;
+              occy[u][half][o.a1 & 31] = o.a1;
+              blk[(size_t) u * 64 + lane] = o;
+            }
+          }
+          prog.insert(prog.end(), blk.begin(), blk.end());
+        }
+        seg.push_back(first_block);
+        seg.push_back(ngroups);
+        seg.push_back(cs);
+        seg.push_back(0);
+      }
+    };
+    build(false, prog_fwd, seg_fwd);
+    build(true, prog_bwd, seg_bwd);
+  }
   mapping_lds.resize((size_t) S);
   for (int i = 0; i < S; i++) mapping_lds[i] = moment_perm[alpha_moment_mapping[i]];
 

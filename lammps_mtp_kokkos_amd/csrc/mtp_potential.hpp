@@ -62,6 +62,12 @@ struct mtp_potential {
   std::vector<int32_t> seed_idx;
   std::vector<double> seed_val;
 
+  // gather programs of the product passes (finalize): operations {a0 = X index, a1 = Y index, mult, a3 = target} in
+  // LDS numbering, 64 per block, blocks in execution order; seg_* = per executed level {first block, groups, chunk
+  // size, 0} (a group = chunk-size consecutive blocks: lane l's chunk is operation l of each of them)
+  std::vector<MtpRow> prog_fwd, prog_bwd;
+  std::vector<int32_t> seg_fwd, seg_bwd;
+
   int finalize(std::string &err);
 };
 
