@@ -33,6 +33,8 @@ def test_committed_potentials_parse_clean_under_sanitizers(exe, fname, sel):
     sizes = json.load(open(os.path.join(POT, "SIZES.json")))[fname]
     b, t, s, a = map(int, out.split()[1:5])
     assert (b, t, s, a) == (sizes["B"], sizes["T"], sizes["S"], sizes["A"])
+    # the gather programs of the product passes reproduce the reference's sequential products and adjoints
+    assert float(out.split()[8]) < 1e-12, out
 
 
 def test_truncated_and_corrupted_files_fail_cleanly(exe, tmp_path):
