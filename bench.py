@@ -149,7 +149,8 @@ def main():
     decomposed = world > 1 or self_halo
     use_rows = decomposed and os.environ.get("MTP_BENCH_OVERLAP", "1") != "0"
     if use_rows:
-        ilist_np, first_np, neigh_np, (n_a, n_b, n_c) = overlap_order(plan)
+        ilist_np, first_np, neigh_np, (n_a, n_b, n_c) = overlap_order(
+            plan, align_rounds=os.environ.get("MTP_BENCH_ALIGN_ROUNDS", "1") != "0")
     else:
         ilist_np, first_np, neigh_np = plan.ilist, plan.first, plan.neigh
         n_a, n_b, n_c = 0, plan.nlocal, 0

@@ -227,7 +227,7 @@ def sub_list(plan: HaloPlan, rows):
     return plan.ilist[rows].astype(np.int32), first, neigh.astype(np.int32)
 
 
-def overlap_order(plan: HaloPlan, round_atoms=3072):
+def overlap_order(plan: HaloPlan, round_atoms=3072, align_rounds=True):
     """Neighbour list of the rank reordered for an overlapped step: rows [0, nA) and the last nC rows are interior
     atoms (no ghost in their list); the rows in between hold the boundary atoms and whatever interior atoms are left.
     The step then runs forward-halo || rows A, middle rows, reverse-halo || rows C (mtp_halo_force_step).  A and C
@@ -235,7 +235,13 @@ def overlap_order(plan: HaloPlan, round_atoms=3072):
     x 12 wavefronts fill the GPU once) -- every extra launch costs a partially filled last round of wavefronts.
     Returns (ilist, first, neigh, (nA, nB, nC))."""
     interior, boundary = split_interior(plan)
-    na = min(len(interior) // 2, int(round_atoms))
+    R = int(round_atoms)
+    # the middle launch in whole rounds of wavefronts where the interior atoms allow it (a launch of 1.5 rounds takes as
+    # long as one of 2); A and C share what is left, at most one round each
+    n_mid = -(-len(boundary) // R) * R
+    spare = plan.nlocal - n_mid
+    na = min(spare // 2, R) if (align_rounds and spare >= 1024) else min(len(interior) // 2, R)
+    na = max(0, min(na, len(interior) // 2))
     nc = na
     order = np.concatenate([interior[:na], boundary, interior[na:len(interior) - nc],
                             interior[len(interior) - nc:]]).astype(np.int64)
