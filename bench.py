@@ -419,6 +419,7 @@ def main():
             "energy_per_atom_eV": energy_per_atom,
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
+    halo = None          # the RCCL communicator goes before the process group and the HIP runtime do
     if world > 1:
         dist.destroy_process_group()
 
