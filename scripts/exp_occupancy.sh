@@ -1,5 +1,5 @@
 #!/bin/bash
-# Experiment: does a third wavefront per SIMD pay?  A level-14 potential (smaller per-atom LDS image) lets 12 wavefronts
+# Experiment (round 2, led to the 12-wavefront plan and the SIMD-balance rule of plan()): does a third wavefront per SIMD pay?  A level-14 potential (smaller per-atom LDS image) lets 12 wavefronts
 # per CU fit today; the 168-VGPR build is timed at 8 and at 12 wavefronts per CU, next to the shipped build.
 OUT=gpurun_out/${1:-occ}
 mkdir -p $OUT
