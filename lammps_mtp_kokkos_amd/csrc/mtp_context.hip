@@ -69,8 +69,8 @@ struct mtp_context {
   DevBuf<double> d_species;
   DevBuf<MtpRow8> d_rows, d_prog_fwd, d_prog_bwd;
   DevBuf<unsigned char> d_blob;
-  DevBuf<int32_t> d_seed_idx, d_map;
-  DevBuf<double> d_seed_val, d_lin;
+  DevBuf<int32_t> d_seed_idx, d_map, d_map_all;
+  DevBuf<double> d_seed_val, d_lin, d_leaf_cf, d_leaf_cb;
   // neighbour list
   DevBuf<int> d_ilist, d_first, d_neigh;
   DevBuf<int> d_nb_scratch, d_nb_info;   // device neighbour-list build
@@ -132,7 +132,8 @@ void mtp_context::plan()
     LaunchPlan &L = lp[which];
     L.tab_rows = 2 * p.slot_count + 3 * P;
     L.g_doubles = 0;
-    const int d_doubles = A;
+    // leaf moments have no LDS slot in force calls; grade calls keep their values (candidate vector), not their adjoints
+    const int d_doubles = p.stored_moment_count, Am = which == 2 ? A : p.stored_moment_count;
     const size_t ints = (size_t) 2 * nt + cap;
     const int grows = p.slot_count * MTP_PITCH;   // g rows; the dg rows take as much again
     const int trows = 2 * grows;
@@ -140,7 +141,7 @@ void mtp_context::plan()
     // Three layouts of the per-atom LDS image (mtp_kernels.hip, WaveLds), sizes in doubles:
     //   keep     [g rows | dg rows | overlay]; coordinate-power rows and moments / adjoints share the overlay
     //            (never live together); the derivative-polynomial coefficients later take the moments' place
-    const int m_keep = std::max(std::max(A, p.coef_total), 16);
+    const int m_keep = std::max(std::max(Am, p.coef_total), 16);
     Layout keep;
     keep.mode = 0;
     keep.pow_row = 2 * p.slot_count;
@@ -166,7 +167,7 @@ void mtp_context::plan()
     //            moments and adjoints then take the front of the region; ahead of the force phase the g and dg rows
     //            are built again (coefficient blocks behind them, D[0, B) in front).  One more pass over the
     //            neighbours' radial functions buys LDS: level 20 goes from 37 to 24 KB per atom.
-    const int m_reb = std::max(A, 16);
+    const int m_reb = std::max(Am, 16);
     Layout reb;
     reb.mode = 2;
     reb.pow_row = p.slot_count;
@@ -294,7 +295,7 @@ void mtp_context::plan()
   }
   base.NT = nt;
   base.cj_cap = cap;
-  base.d_doubles = A;
+  base.d_doubles = p.stored_moment_count;
 }
 
 extern "C" {
@@ -332,7 +333,7 @@ int mtp_potential_get_info(const mtp_potential *p, mtp_potential_info *info)
   info->coeff_count = p->coeff_count;
   info->has_selection = p->has_selection;
   info->configuration_mode = p->configuration_mode;
-  info->product_levels = (int) p->level_offset.size() - 1;
+  info->product_levels = p->normal_levels;
   info->scaling = p->scaling;
   info->min_cutoff = p->min_cutoff;
   info->max_cutoff = p->max_cutoff;
@@ -457,24 +458,30 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     bb.off_slot = put(slot_pad.data(), slot_pad.size() * sizeof(int32_t));
     bb.off_radial = put(pot->radial_basis_coeffs.data(), pot->radial_basis_coeffs.size() * sizeof(double));
     // scalar-side tables (24 B per basis function): LDS when they are small, HBM/L2 otherwise
-    bb.scalars_in_lds = (pot->alpha_scalar_count + pot->seed_idx.size()) * 12 <= 4096;
+    bb.scalars_in_lds = (pot->e_map.size() + pot->seed_idx.size()) * 12 <= 4096;
     if (const char *e = std::getenv("MTP_SCALARS_LDS")) bb.scalars_in_lds = std::atoi(e) != 0;   // tuning override
     if (bb.scalars_in_lds) {
       bb.off_seed_idx = put(pot->seed_idx.data(), pot->seed_idx.size() * sizeof(int32_t));
       bb.off_seed_val = put(pot->seed_val.data(), pot->seed_val.size() * sizeof(double));
-      bb.off_map = put(pot->mapping_lds.data(), pot->mapping_lds.size() * sizeof(int32_t));
-      bb.off_lin = put(pot->linear_coeffs.data(), pot->linear_coeffs.size() * sizeof(double));
+      bb.off_map = put(pot->e_map.data(), pot->e_map.size() * sizeof(int32_t));
+      bb.off_lin = put(pot->e_lin.data(), pot->e_lin.size() * sizeof(double));
     } else {
       bb.off_seed_idx = bb.off_seed_val = bb.off_map = bb.off_lin = 0;
     }
     c->d_seed_idx.upload(pot->seed_idx, st);
     c->d_seed_val.upload(pot->seed_val, st);
-    c->d_map.upload(pot->mapping_lds, st);
-    c->d_lin.upload(pot->linear_coeffs, st);
+    c->d_map.upload(pot->e_map, st);
+    c->d_lin.upload(pot->e_lin, st);
+    c->d_map_all.upload(pot->mapping_lds, st);
+    c->d_leaf_cf.upload(pot->leaf_cf, st);
+    c->d_leaf_cb.upload(pot->leaf_cb, st);
     bb.g_seed_idx = c->d_seed_idx.ptr;
     bb.g_seed_val = c->d_seed_val.ptr;
     bb.g_map = c->d_map.ptr;
     bb.g_lin = c->d_lin.ptr;
+    bb.g_map_all = c->d_map_all.ptr;
+    bb.leaf_cf = c->d_leaf_cf.ptr;
+    bb.leaf_cb = c->d_leaf_cb.ptr;
     bb.off_pack = put(pot->basic_pack_lds.data(), pot->basic_pack_lds.size() * sizeof(int32_t));
     bb.off_coef = put(pot->basic_tgt.data(), pot->basic_tgt.size() * sizeof(int32_t));
     bb.off_smu = put(pot->slot_mu.data(), pot->slot_mu.size() * sizeof(int32_t));
@@ -533,8 +540,11 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
       b.deg_first[d] = pot->deg_first[d];
       b.deg_coef[d] = pot->deg_coef[d];
     }
-    b.nlevels = (int) pot->level_offset.size() - 1;
+    b.nlevels = pot->normal_levels;   // (the level table has one more entry: the leaf rows)
     b.nseed = (int) pot->seed_idx.size();
+    b.Ad = pot->stored_moment_count;
+    b.Am = b.Ad;                      // per launch: the grade instantiation keeps the leaves' values too
+    b.Se = (int) pot->e_map.size();
     b.rmin = pot->min_cutoff;
     b.rmax = pot->max_cutoff;
     b.scaling = pot->scaling;
@@ -839,6 +849,7 @@ int mtp_compute_device_rows(mtp_context *c, void *stream, int row_begin, int row
   };
   p.tab_rows = L.tab_rows;
   p.m_doubles = L.m_doubles;
+  p.Am = grade_flag ? c->pot->alpha_moment_count : c->pot->stored_moment_count;
   p.ov_doubles = L.ov_doubles;
   p.rebuild_tables = L.rebuild ? 1 : 0;
   p.rows_in_lds = L.rows_lds ? 1 : 0;

@@ -21,6 +21,13 @@ struct MtpDevParams {
   // potential sizes
   int Sp, R, Mu, P, A, B, T, S, C;
   int nslot, nlevels, nseed;
+  // leaf moments (mtp_potential.hpp) have no LDS slot in force calls: Ad = stored moments (adjoint extent), Am = moment
+  // extent of this launch (Ad; A in grade calls, which put the leaves' values into the candidate vector), Se = scalars
+  // of stored moments (the energy tables map / lin and the seeds list only those); nlevels = dependency levels, the
+  // leaf rows are entry [nlevels] of the level table, their constants leaf_cf / leaf_cb (HBM / L2) one per padded row
+  int Am, Ad, Se;
+  const double *leaf_cf, *leaf_cb;
+  const int *g_map_all;    // int[S]: every scalar's moment (grade calls)
   // slots are numbered by tensor rank: rank d owns slots [deg_first[d], deg_first[d+1]); the force phase keeps
   // one block of derivative-polynomial coefficients per slot (1 double for rank 0, 3*d*(d+1)/2 for rank d:
   // x-, y-, z-derivative, each over the monomials of degree d-1), rank d's blocks starting at deg_coef[d]
@@ -33,13 +40,13 @@ struct MtpDevParams {
   const unsigned char *blob;
   int blob_bytes;          // multiple of 16
   int off_rows;            // MtpRow8[T]   (only when rows_in_lds)
-  int off_level;           // int[nlevels+1]
+  int off_level;           // int[nlevels+2]
   int off_slot;            // int[Mu][MTP_PSTRIDE], -1 padded, 16-byte aligned
   int off_radial;          // double[Sp*Sp*Mu*R]
   int off_seed_idx;        // int[nseed]
   int off_seed_val;        // double[nseed]
-  int off_map;             // int[S]
-  int off_lin;             // double[S]
+  int off_map;             // int[Se]
+  int off_lin;             // double[Se]
   int off_pack;            // int[B] slot | a<<8 | b<<12 | c<<16 | mu<<20
   int off_fwd;             // int[nfb][8] head x tail blocks of the basic-moment pass (mtp_potential.hpp)
   int nfb;                 // number of those blocks

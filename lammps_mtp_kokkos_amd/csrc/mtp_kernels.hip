@@ -374,6 +374,69 @@ __device__ __forceinline__ void products_backward(const MtpRow8 *rows, const int
   }
 }
 
+// Leaf rows (mtp_potential.hpp: products that no row reads, i.e. scalars of the basis; pair_mtp.cpp:204-233).  Their
+// moments have no LDS slot in force calls.  Forward: the row's product goes straight into the site energy,
+// e += cf M[a0] M[a1] with cf = linear coefficient x mult (grade calls also keep M[a3] += mult M[a0] M[a1]: the
+// candidate vector lists the leaves' values).  Reverse: D[a0] += cb M[a1], D[a1] += cb M[a0] with the constant adjoint
+// cb = seed(a3) x mult -- no D[a3] read.  Row per lane as above; the constants come from HBM / L2, lane-contiguous.
+template <int U, bool STORE>
+__device__ __forceinline__ double leaf_forward(const MtpRow8 *rows, const double *cf, int beg, int nit, double *M, int lane)
+{
+  double e = 0.0;
+  const MtpRow8 *rp = rows + beg + lane;
+  const double *cp = cf + lane;
+  for (int it = 0; it < nit; it += U) {
+    MtpRow8 rw[U];
+    double c[U], v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int b = 64 * min(it + u, nit - 1);   // uniform clamp: the tail re-reads the last block
+      rw[u] = rp[b];
+      c[u] = cp[b];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = M[rw[u].lo & 0xffffu] * M[rw[u].lo >> 16];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (it + u < nit) {   // uniform branch
+        e = fma(c[u], v[u], e);
+        if (STORE) lds_add(&M[rw[u].hi & 0xffffu], (double) ((int) rw[u].hi >> 16) * v[u]);
+      }
+  }
+  if (STORE) wave_fence();
+  return e;
+}
+
+template <int U>
+__device__ __forceinline__ void leaf_backward(const MtpRow8 *rows, const double *cb, int beg, int nit, const double *M,
+                                              double *D, int lane)
+{
+  const MtpRow8 *rp = rows + beg + lane;
+  const double *cp = cb + lane;
+  for (int it = 0; it < nit; it += U) {
+    MtpRow8 rw[U];
+    double c[U], m0[U], m1[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int b = 64 * min(it + u, nit - 1);
+      rw[u] = rp[b];
+      c[u] = cp[b];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      m0[u] = M[rw[u].lo & 0xffffu];
+      m1[u] = M[rw[u].lo >> 16];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (it + u < nit) {
+        lds_add(&D[rw[u].lo >> 16], c[u] * m0[u]);
+        lds_add(&D[rw[u].lo & 0xffffu], c[u] * m1[u]);
+      }
+  }
+  wave_fence();
+}
+
 // Phase 4, gather form (round 2).  A level of a pass is a list of chunks; lane l of a group of 64 lanes runs one chunk:
 // acc = sum_u mult_u X[o0_u] Y[o1_u] over its CS operations, then ONE atomic add T[tgt] += acc.  Forward: X = Y = T =
 // moments (rows of one target); reverse: X = adjoints, Y = moments, T = adjoints (the terms of one destination), so a
@@ -802,8 +865,8 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
         if (NG >= 4) acc[t][e] = pair_sum16(acc[t][e]);   // KL = 16: groups differ in lane bits 4 and 5
         if (NG >= 2) acc[t][e] = pair_sum32(acc[t][e]);
       }
-    for (int m = kp->B + lane; m < kp->A; m += 64) w.M[m] = 0.0;
-    for (int m = lane; m < kp->A; m += 64) w.D[m] = 0.0;
+    for (int m = kp->B + lane; m < kp->Am; m += 64) w.M[m] = 0.0;
+    for (int m = lane; m < kp->Ad; m += 64) w.D[m] = 0.0;
     if (q == 0) {
 #pragma unroll
       for (int t = 0; t < NB; t++)
@@ -828,24 +891,27 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       else products_forward<MTP_PU>(kp->rows, bt.level, kp->nlevels, w.M, lane);
     }
 #endif
+    // ---- site energy (pair_mtp.cpp:204-212): the leaf rows' share first ------------------------------------
+    double e = 0.0;
+    // (two code paths per table home, LDS blob or HBM/L2: no pointer selects between address spaces, see below)
+    const int leaf_beg = __builtin_amdgcn_readfirstlane(bt.level[kp->nlevels]);
+    const int leaf_nit = (__builtin_amdgcn_readfirstlane(bt.level[kp->nlevels + 1]) - leaf_beg) >> 6;
+#ifndef MTP_EXP_NOPRODUCTS
+    if (rows_lds) e = leaf_forward<MTP_PU, GRADE>(bt.rows, kp->leaf_cf, leaf_beg, leaf_nit, w.M, lane);
+    else e = leaf_forward<MTP_PU, GRADE>(kp->rows, kp->leaf_cf, leaf_beg, leaf_nit, w.M, lane);
+#endif
     STAMP(4);   // products forward
     KP_FRESH();
     // ---- candidate vector, species and linear blocks (pair_mtp_extrapolation.cpp:235-252) ----
     if (GRADE) {
       double *crow = kp->cvec + (size_t) ii * kp->cpad + kp->Sp * kp->Sp * kp->Mu * kp->R;
       for (int k = lane; k < kp->Sp; k += 64) crow[k] = k == itype ? 1.0 : 0.0;
-      if (MTP_SCALARS_COND)
-        for (int k = lane; k < kp->S; k += 64) crow[kp->Sp + k] = w.M[bt.map[k]];
-      else
-        for (int k = lane; k < kp->S; k += 64) crow[kp->Sp + k] = w.M[kp->g_map[k]];
+      for (int k = lane; k < kp->S; k += 64) crow[kp->Sp + k] = w.M[kp->g_map_all[k]];
     }
-    // ---- site energy (pair_mtp.cpp:204-212) ----------------------------------------------
-    double e = 0.0;
-    // (two code paths per table home, LDS blob or HBM/L2: no pointer selects between address spaces, see below)
     if (MTP_SCALARS_COND)
-      for (int k = lane; k < kp->S; k += 64) e += bt.lin[k] * w.M[bt.map[k]];
+      for (int k = lane; k < kp->Se; k += 64) e += bt.lin[k] * w.M[bt.map[k]];
     else
-      for (int k = lane; k < kp->S; k += 64) e += kp->g_lin[k] * w.M[kp->g_map[k]];
+      for (int k = lane; k < kp->Se; k += 64) e += kp->g_lin[k] * w.M[kp->g_map[k]];
     if (e_per_atom) e = wave_sum(e) + kp->species_coeffs[itype];
     else eacc += e + (lane == 0 ? kp->species_coeffs[itype] : 0.0);
     // ---- 4b. adjoints (pair_mtp.cpp:217-233) ----------------------------------------------
@@ -857,6 +923,8 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     STAMP(5);   // energy + seeds
     KP_FRESH();
 #ifndef MTP_EXP_NOPRODUCTS
+    if (rows_lds) leaf_backward<MTP_PU>(bt.rows, kp->leaf_cb, leaf_beg, leaf_nit, w.M, w.D, lane);
+    else leaf_backward<MTP_PU>(kp->rows, kp->leaf_cb, leaf_beg, leaf_nit, w.M, w.D, lane);
     if constexpr (GATHER) {
       gather_pass(kp->prog_bwd, bt.seg_bwd, kp->nlevels, w.D, w.M, w.D, lane);
     } else {

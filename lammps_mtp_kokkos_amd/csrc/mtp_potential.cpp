@@ -342,9 +342,6 @@ int mtp_potential::finalize(std::string &err)
     err = "tensor rank above 11 is not supported by this build";
     return MTP_ERR_LIMIT;
   }
-  std::vector<int> wlevel((size_t) A, 0), rlevel((size_t) A, 0);
-  std::vector<int> lvl((size_t) T, 0);
-  int nlev = 0;
   for (int k = 0; k < T; k++) {
     const int32_t *q = &alpha_index_times[4 * (size_t) k];
     for (int j : {0, 1, 3})
@@ -352,6 +349,32 @@ int mtp_potential::finalize(std::string &err)
         err = "alpha_index_times refers to a moment outside alpha_moments_count";
         return MTP_ERR_TABLE;
       }
+  }
+  // leaf moments (mtp_potential.hpp): written by rows, never read by one, not a basic.  Their rows are deferred to the
+  // end of the forward pass, which keeps the reference's in-order semantics only if no later row still adds to one of
+  // the row's factors: a leaf with such a row stays an ordinary stored moment.
+  std::vector<char> leaf((size_t) A, 0);
+  if (!std::getenv("MTP_NO_LEAF")) {
+    std::vector<char> is_factor((size_t) A, 0), is_target((size_t) A, 0);
+    std::vector<int> last_write((size_t) A, -1);
+    for (int k = 0; k < T; k++) {
+      const int32_t *q = &alpha_index_times[4 * (size_t) k];
+      is_factor[q[0]] = is_factor[q[1]] = 1;
+      is_target[q[3]] = 1;
+      last_write[q[3]] = k;
+    }
+    for (int m = B; m < A; m++) leaf[m] = is_target[m] && !is_factor[m];
+    for (int k = 0; k < T; k++) {
+      const int32_t *q = &alpha_index_times[4 * (size_t) k];
+      if (leaf[q[3]] && (last_write[q[0]] > k || last_write[q[1]] > k)) leaf[q[3]] = 0;
+    }
+  }
+  std::vector<int> wlevel((size_t) A, 0), rlevel((size_t) A, 0);
+  std::vector<int> lvl((size_t) T, 0);
+  int nlev = 0;
+  for (int k = 0; k < T; k++) {
+    const int32_t *q = &alpha_index_times[4 * (size_t) k];
+    if (leaf[q[3]]) continue;
     int l = std::max(wlevel[q[0]], wlevel[q[1]]) + 1;   // operands complete
     l = std::max(l, rlevel[q[3]] + 1);                  // earlier readers of a3 come first
     lvl[k] = l;
@@ -360,6 +383,10 @@ int mtp_potential::finalize(std::string &err)
     rlevel[q[1]] = std::max(rlevel[q[1]], l);
     nlev = std::max(nlev, l);
   }
+  normal_levels = nlev;
+  nlev++;   // the leaf rows: one more "level" behind the others (possibly empty)
+  for (int k = 0; k < T; k++)
+    if (leaf[alpha_index_times[4 * (size_t) k + 3]]) lvl[k] = nlev;
   level_offset.assign((size_t) nlev + 1, 0);
   for (int k = 0; k < T; k++) level_offset[lvl[k]]++;        // counts at [1..nlev]
   for (int l = 1; l <= nlev; l++) level_offset[l] += level_offset[l - 1];
@@ -404,8 +431,10 @@ int mtp_potential::finalize(std::string &err)
             int cost = 0;
             cost += (rd0[r.a0 & 31] >= 0 && rd0[r.a0 & 31] != r.a0);
             cost += (rd1[r.a1 & 31] >= 0 && rd1[r.a1 & 31] != r.a1);
-            cost += (rd3[r.a3 & 31] >= 0 && rd3[r.a3 & 31] != r.a3);
-            cost += 2 * (at3[r.a3 & 15] >= 0);            // forward ds_add target
+            if (l < nlev) {   // (leaf rows neither read D[a3] nor add into M[a3])
+              cost += (rd3[r.a3 & 31] >= 0 && rd3[r.a3 & 31] != r.a3);
+              cost += 2 * (at3[r.a3 & 15] >= 0);            // forward ds_add target
+            }
             cost += (at0[r.a0 & 15] >= 0) + (at1[r.a1 & 15] >= 0);   // backward ds_add targets
             if (cost < best_cost) {
               best_cost = cost;
@@ -432,13 +461,17 @@ int mtp_potential::finalize(std::string &err)
   // Pad every level to whole 64-row blocks with neutral rows (multiplicity 0, operands = target, a
   // different moment in every lane): the product kernels then run without bounds checks or lane masks.
   {
+    std::vector<int> stored;   // (file numbering; the leaves have no LDS slot a padding row could touch)
+    for (int m = 0; m < A; m++)
+      if (!leaf[m]) stored.push_back(m);
+    if (stored.empty()) stored.push_back(0);
     std::vector<MtpRow> padded;
     std::vector<int32_t> off((size_t) nlev + 1, 0);
     for (int l = 1; l <= nlev; l++) {
       const int b = level_offset[l - 1], e = level_offset[l];
       padded.insert(padded.end(), rows_by_level.begin() + b, rows_by_level.begin() + e);
       while ((int) padded.size() % 64 != 0) {
-        const int t = ((int) padded.size() % 64) % A;
+        const int t = stored[(size_t) ((int) padded.size() % 64) % stored.size()];
         padded.push_back(MtpRow{t, t, 0, t});
       }
       off[l] = (int32_t) padded.size();
@@ -458,7 +491,7 @@ int mtp_potential::finalize(std::string &err)
     seed_idx.clear();
     seed_val.clear();
     for (int m = 0; m < A; m++)
-      if (last[m] >= 0) {
+      if (last[m] >= 0 && !leaf[m]) {
         seed_idx.push_back(m);
         seed_val.push_back(linear_coeffs[last[m]]);
       }
@@ -470,8 +503,20 @@ int mtp_potential::finalize(std::string &err)
   // moments -- basics among [0, B), products among [B, A), so the zero-fill and the k < B loops of the kernel keep
   // working -- by pairwise swaps that lower the modelled extra cycles.  Deterministic (fixed-seed LCG).
   // moment_perm[file index] = LDS index; every device table below is written in LDS numbering.
+  // The leaves take the numbers behind the stored moments (only grade calls give them LDS slots).
   moment_perm.resize((size_t) A);
-  for (int m = 0; m < A; m++) moment_perm[m] = m;
+  std::vector<int> cls_members[3];   // 0 basics, 1 stored products, 2 leaves (file indices)
+  {
+    int nstored = B;
+    for (int m = B; m < A; m++) nstored += !leaf[m];
+    stored_moment_count = nstored;
+    int next_stored = B, next_leaf = nstored;
+    for (int m = 0; m < A; m++) {
+      moment_perm[m] = m < B ? m : (leaf[m] ? next_leaf++ : next_stored++);
+      cls_members[m < B ? 0 : (leaf[m] ? 2 : 1)].push_back(m);
+    }
+  }
+  const int leaf_row0 = level_offset[(size_t) nlev - 1];   // first (padded) row of the leaf block
   if (A >= 2 && !rows_by_level.empty() && !std::getenv("MTP_NO_RENUMBER")) {
     struct Access {
       int nbk, w;
@@ -487,7 +532,7 @@ int mtp_potential::finalize(std::string &err)
     // reads of one address broadcast (count distinct moments); adds to one address serialise (count rows)
     auto group_cost = [&](int r0, int grp, int nbk, const int w3[3], bool distinct) {
       int c = 0;
-      for (int st = 0; st < 3; st++) {
+      for (int st = 0; st < (r0 >= leaf_row0 ? 2 : 3); st++) {   // (leaf rows: no access to their target)
         int seen[32], ns = 0;
         uint8_t h[32] = {0};
         for (int r = r0; r < r0 + grp; r++) {
@@ -521,7 +566,7 @@ int mtp_potential::finalize(std::string &err)
       auto add_accesses = [&](int grp, int nbk, const int w3[3], bool distinct) {
         const int ngroups = (int) rows_by_level.size() / grp;
         for (int g = 0; g < ngroups; g++)
-          for (int st = 0; st < 3; st++) {
+          for (int st = 0; st < (grp * g >= leaf_row0 ? 2 : 3); st++) {
             const int id = (int) acc.size();
             acc.push_back({nbk, w3[st]});
             hist.resize(hist.size() + 32, 0);
@@ -572,14 +617,10 @@ int mtp_potential::finalize(std::string &err)
       };
       const long long trials = std::min<long long>(200ll * A, 300000ll);
       for (long long t = 0; t < trials; t++) {
-        int m1 = (int) (next() % (uint32_t) A), m2;
-        if (m1 < B) {
-          if (B < 2) continue;
-          m2 = (int) (next() % (uint32_t) B);
-        } else {
-          if (A - B < 2) continue;
-          m2 = B + (int) (next() % (uint32_t) (A - B));
-        }
+        const int m1 = (int) (next() % (uint32_t) A);
+        const std::vector<int> &cls = cls_members[m1 < B ? 0 : (leaf[m1] ? 2 : 1)];   // numbers swap inside a class only
+        if (cls.size() < 2) continue;
+        const int m2 = cls[next() % (uint32_t) cls.size()];
         if (m1 == m2) continue;
         const int p1 = moment_perm[m1], p2 = moment_perm[m2];
         if (move_delta(m1, p1, p2, m2) + move_delta(m2, p2, p1, m1) >= 0) continue;
@@ -610,12 +651,36 @@ int mtp_potential::finalize(std::string &err)
     if (std::getenv("MTP_DEBUG_BANKS"))
       std::fprintf(stderr, "mtp: LDS bank model of the product passes: %lld -> %lld extra cycles per atom\n", cost_before,
                    total_cost());
-    for (MtpRow &row : rows_by_level) {
-      row.a0 = moment_perm[row.a0];
-      row.a1 = moment_perm[row.a1];
-      row.a3 = moment_perm[row.a3];
+  }
+  for (MtpRow &row : rows_by_level) {
+    row.a0 = moment_perm[row.a0];
+    row.a1 = moment_perm[row.a1];
+    row.a3 = moment_perm[row.a3];
+  }
+  for (int32_t &m : seed_idx) m = moment_perm[m];
+  {   // constants of the leaf rows and the energy tables of the stored scalars
+    std::vector<double> c_energy((size_t) A, 0.0), c_seed((size_t) A, 0.0);   // by LDS number
+    e_map.clear();
+    e_lin.clear();
+    for (int i = 0; i < S; i++) {
+      const int m = alpha_moment_mapping[i], ml = moment_perm[m];
+      if (leaf[m]) {
+        c_energy[(size_t) ml] += linear_coeffs[i];
+        c_seed[(size_t) ml] = linear_coeffs[i];   // the last one wins (:217-218)
+      } else {
+        e_map.push_back(ml);
+        e_lin.push_back(linear_coeffs[i]);
+      }
     }
-    for (int32_t &m : seed_idx) m = moment_perm[m];
+    const size_t nleaf_rows = rows_by_level.size() - (size_t) leaf_row0;
+    leaf_cf.assign(nleaf_rows, 0.0);
+    leaf_cb.assign(nleaf_rows, 0.0);
+    for (size_t r = 0; r < nleaf_rows; r++) {
+      const MtpRow &row = rows_by_level[(size_t) leaf_row0 + r];
+      if (row.mult == 0) continue;   // padding
+      leaf_cf[r] = c_energy[(size_t) row.a3] * row.mult;
+      leaf_cb[r] = c_seed[(size_t) row.a3] * row.mult;
+    }
   }
   // ---- gather programs of the product passes ---------------------------------------------------------------------
   // The product passes as the kernel runs them (mtp_kernels.hip, gather_pass): per level a list of *chunks*; a chunk
@@ -627,7 +692,8 @@ int mtp_potential::finalize(std::string &err)
   // (2 per read, 15 per atomic add, padding included); chunks are dealt to lanes greedily so that the operands of one
   // wave instruction spread over the LDS banks (reads: 32 lanes over 32 eight-byte banks, adds: 16 lanes over 16).
   {
-    const int nlev2 = (int) level_offset.size() - 1;
+    const int nlev2 = normal_levels;   // (the leaf rows keep the row-per-lane form: no target to share)
+    const int A_st = stored_moment_count;
     auto build = [&](bool reverse, std::vector<MtpRow> &prog, std::vector<int32_t> &seg) {
       prog.clear();
       seg.clear();
@@ -721,7 +787,7 @@ int mtp_potential::finalize(std::string &err)
               while (scan_from < chunks.size() && used[scan_from]) scan_from++;
             } else {   // padding chunk: adds 0.0 to a moment whose add bank is still free in this 16-lane group
               int t = 0;
-              for (int m = 0; m < A; m++)
+              for (int m = 0; m < A_st; m++)
                 if (occt[q16][m & 15] < 0) {
                   t = m;
                   break;

@@ -68,6 +68,19 @@ struct mtp_potential {
   std::vector<MtpRow> prog_fwd, prog_bwd;
   std::vector<int32_t> seg_fwd, seg_bwd;
 
+  // Leaf moments: products that times rows write but never read (always scalars of the basis: pair_mtp.cpp:204-233
+  // uses them in the energy sum and as adjoint seeds only).  Neither their value nor their adjoint needs an LDS slot:
+  // a row into leaf t adds linear_coeff(t) mult M[a0] M[a1] to the site energy and its reverse terms are
+  // D[a0] += seed(t) mult M[a1], D[a1] += seed(t) mult M[a0] with a constant seed.  The leaf rows are the LAST entry of
+  // level_offset (after the normal_levels dependency levels; possibly empty), leaf_cf / leaf_cb hold the two constants
+  // per row of that block (energy: sum of the coefficients mapped to t; adjoint: the last one, :217-218), and the
+  // leaves are numbered [stored_moment_count, A) in LDS numbering (only grade calls keep their values: candidate vector).
+  // e_map / e_lin / seed_* list the scalars of stored moments only; mapping_lds keeps all of them.
+  int stored_moment_count = 0, normal_levels = 0;
+  std::vector<double> leaf_cf, leaf_cb;
+  std::vector<int32_t> e_map;
+  std::vector<double> e_lin;
+
   int finalize(std::string &err);
 };
 
