@@ -63,13 +63,15 @@ struct mtp_context {
   std::string last_error;
   int variant = MTP_VARIANT_AUTO;
   int num_cus = 256;
-  int blob_bytes_norows = 0, blob_bytes_rows = 0;   // LDS table blob without / with the packed times rows
+  // LDS table blob: the pieces a launch plan may leave in HBM / L2 are its tail -- [core | adjoint scatter targets |
+  // basic descriptors (candidate-vector kernel) | packed times rows]; a plan copies one of these four prefixes
+  int blob_bytes_core = 0, blob_bytes_tgt = 0, blob_bytes_norows = 0, blob_bytes_rows = 0;
   bool xcd_map = true;   // MTP_XCD_MAP=0 (tuning override) turns the XCD-aware atom map off
   // potential tables
   DevBuf<double> d_species;
   DevBuf<MtpRow8> d_rows, d_prog_fwd, d_prog_bwd;
   DevBuf<unsigned char> d_blob;
-  DevBuf<int32_t> d_seed_idx, d_map, d_map_all;
+  DevBuf<int32_t> d_seed_idx, d_map, d_map_all, d_tgt;
   DevBuf<double> d_seed_val, d_lin, d_leaf_cf, d_leaf_cb;
   // neighbour list
   DevBuf<int> d_ilist, d_first, d_neigh;
@@ -99,7 +101,8 @@ struct mtp_context {
     int wpb = 1, grid = 1, wave_doubles = 0, tab_rows = 0, g_doubles = 0, m_doubles = 0, ov_doubles = 0;
     bool rebuild = false;
     int wps = 2;
-    bool rows_lds = false;
+    bool rows_lds = false, tgt_lds = true;
+    int blob_bytes = 0;   // the blob prefix this plan copies
     size_t lds_bytes = 0;
   } lp[3];   // [0] force calls (wavefront per atom), [1] candidate-vector kernel of grade calls, [2] the fused kernel's
              // grade instantiation (planned without the 3-per-SIMD build: at 168 VGPRs it spills 52 dwords and is slower)
@@ -124,9 +127,9 @@ void mtp_context::plan()
   const int A = p.alpha_moment_count, P = p.max_alpha_index_basic;
   int KL = 16, KB = 1;
   (void) mtp_pick_shape(p.alpha_index_basic_count, &KL, &KB);
-  const int cap = std::max(64, (max_numneigh + 63) / 64 * 64);
+  const int cap = std::max(64, (max_numneigh + 31) / 32 * 32);
   const size_t LDS = 160 * 1024;
-  size_t blob = (size_t) blob_bytes_norows;   // without the packed rows; a plan adds them when they come for free
+  size_t blob = (size_t) blob_bytes_core;   // the shape is planned with the smallest prefix; what still fits is added then
   const int nt = 32;
   for (int which : {0, 2}) {   // [0] fused force kernel, [2] its grade instantiation
     LaunchPlan &L = lp[which];
@@ -268,11 +271,14 @@ void mtp_context::plan()
     }
     const int blocks_per_cu = std::max(1, best / best_w);
     // packed times rows in LDS when the chosen shape still fits with them (or when they are tiny)
-    L.rows_lds = (size_t) blocks_per_cu * ((size_t) blob_bytes_rows + best_w * wb) <= LDS;
+    auto fits = [&](int bytes) { return (size_t) blocks_per_cu * ((size_t) bytes + best_w * wb) <= LDS; };
+    L.rows_lds = fits(blob_bytes_rows);
     if (const char *e = std::getenv("MTP_ROWS_LDS")) L.rows_lds = L.rows_lds && std::atoi(e) != 0;   // tuning override
+    L.tgt_lds = L.rows_lds || fits(blob_bytes_tgt);
+    L.blob_bytes = L.rows_lds ? blob_bytes_rows : (fits(blob_bytes_norows) ? blob_bytes_norows : (L.tgt_lds ? blob_bytes_tgt : blob_bytes_core));
     L.wpb = best_w;
     L.wave_doubles = (int) (wb / 8);
-    L.lds_bytes = (L.rows_lds ? (size_t) blob_bytes_rows : blob) + wb * best_w;
+    L.lds_bytes = (size_t) L.blob_bytes + wb * best_w;
     const int need = (inum + best_w - 1) / best_w;
     L.grid = std::max(1, std::min(need, num_cus * blocks_per_cu));
   }
@@ -282,11 +288,12 @@ void mtp_context::plan()
     const size_t dbl = (size_t) KL * KB + (size_t) (4 * P + R) * (nt + 2) + 4 * (size_t) nt + (size_t) Mu * nt + (size_t) Sp * Mu * R;
     const size_t ints = (size_t) nt + cap;
     const size_t wb = (dbl * 8 + ints * 4 + 15) / 16 * 16;
+    const size_t blob1 = (size_t) blob_bytes_norows;   // (this kernel reads the basic descriptors)
     int w = 8;
-    while (w > 1 && blob + w * wb > LDS) w--;
+    while (w > 1 && blob1 + w * wb > LDS) w--;
     L.wpb = w;
     L.wave_doubles = (int) (wb / 8);
-    L.lds_bytes = blob + wb * w;
+    L.lds_bytes = blob1 + wb * w;
     const int blocks_per_cu = std::max<int>(1, std::min<int>(8 / w, (int) (LDS / L.lds_bytes)));
     L.grid = std::max(1, std::min((inum + w - 1) / w, num_cus * blocks_per_cu));
     L.tab_rows = 4 * P + R;
@@ -482,11 +489,17 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     bb.g_map_all = c->d_map_all.ptr;
     bb.leaf_cf = c->d_leaf_cf.ptr;
     bb.leaf_cb = c->d_leaf_cb.ptr;
-    bb.off_pack = put(pot->basic_pack_lds.data(), pot->basic_pack_lds.size() * sizeof(int32_t));
-    bb.off_coef = put(pot->basic_tgt.data(), pot->basic_tgt.size() * sizeof(int32_t));
     bb.off_smu = put(pot->slot_mu.data(), pot->slot_mu.size() * sizeof(int32_t));
     bb.off_fwd = put(pot->fwd_blocks.data(), pot->fwd_blocks.size() * sizeof(int32_t));
     bb.nfb = pot->fwd_block_count;
+    blob.resize((blob.size() + 15) / 16 * 16, 0);
+    c->blob_bytes_core = (int) blob.size();
+    bb.off_coef = put(pot->basic_tgt.data(), pot->basic_tgt.size() * sizeof(int32_t));
+    c->d_tgt.upload(pot->basic_tgt, st);
+    bb.g_tgt = c->d_tgt.ptr;
+    blob.resize((blob.size() + 15) / 16 * 16, 0);
+    c->blob_bytes_tgt = (int) blob.size();
+    bb.off_pack = put(pot->basic_pack_lds.data(), pot->basic_pack_lds.size() * sizeof(int32_t));
     blob.resize((blob.size() + 15) / 16 * 16, 0);
     c->blob_bytes_norows = (int) blob.size();
     bb.off_rows = put(rows8.data(), rows8.size() * sizeof(MtpRow8));
@@ -838,7 +851,7 @@ int mtp_compute_device_rows(mtp_context *c, void *stream, int row_begin, int row
     const int small = L.wps == 3 ? 4 : 2;   // (multiples of 4 keep the SIMDs balanced at 3 per SIMD)
     if (small < wpb_launch) wpb_launch = small;
   }
-  const size_t blob_launch = L.rows_lds ? (size_t) c->blob_bytes_rows : (size_t) c->blob_bytes_norows;
+  const size_t blob_launch = (size_t) L.blob_bytes;
   const size_t lds_launch = blob_launch + (size_t) wpb_launch * L.wave_doubles * 8;
   auto grid_for = [&](const mtp_context::LaunchPlan &lp_, int wpb_) {
     int g = (row_count + wpb_ - 1) / wpb_;
@@ -853,7 +866,8 @@ int mtp_compute_device_rows(mtp_context *c, void *stream, int row_begin, int row
   p.ov_doubles = L.ov_doubles;
   p.rebuild_tables = L.rebuild ? 1 : 0;
   p.rows_in_lds = L.rows_lds ? 1 : 0;
-  p.blob_bytes = L.rows_lds ? c->blob_bytes_rows : c->blob_bytes_norows;
+  p.blob_bytes = L.blob_bytes;
+  p.tgt_in_lds = L.tgt_lds ? 1 : 0;
   p.dg_mode = L.layout.mode;
   p.pow_row = L.layout.pow_row;
   p.dg_off = L.layout.dg_off;

@@ -53,6 +53,8 @@ struct MtpDevParams {
   int off_smu;             // int[nslot] radial function index mu of each slot
   int off_coef;            // int2[B] scatter targets of each basic's adjoint: {tx | ty << 16, tz | fa << 16 | fb << 20 | fc << 24}
   int rows_in_lds;
+  int tgt_in_lds;          // the scatter targets (off_coef) are in the blob prefix of this launch; else read g_tgt (HBM / L2)
+  const int *g_tgt;
   // scalar map / linear coefficients / adjoint seeds: in the blob when small, else read from HBM/L2 once per atom
   // (at level 20 they are 11 KB, the difference between 3 and 4 wavefronts per CU)
   int scalars_in_lds;

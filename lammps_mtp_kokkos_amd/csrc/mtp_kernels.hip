@@ -946,12 +946,15 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       constexpr int ROUNDS = 3;   // 192 basics per trip: all reads first, one LDS round trip
       double dd[ROUNDS];
       int2 tg[ROUNDS];
+      if (kp->tgt_in_lds) {   // (uniform; two loops, not a pointer select between address spaces)
 #pragma unroll
-      for (int u = 0; u < ROUNDS; u++) {
-        const int k = k0 + lane + 64 * u, kc = min(k, kp->B - 1);
-        dd[u] = w.D[kc];
-        tg[u] = reinterpret_cast<const int2 *>(bt.coef)[kc];
+        for (int u = 0; u < ROUNDS; u++) tg[u] = reinterpret_cast<const int2 *>(bt.coef)[min(k0 + lane + 64 * u, kp->B - 1)];
+      } else {
+#pragma unroll
+        for (int u = 0; u < ROUNDS; u++) tg[u] = reinterpret_cast<const int2 *>(kp->g_tgt)[min(k0 + lane + 64 * u, kp->B - 1)];
       }
+#pragma unroll
+      for (int u = 0; u < ROUNDS; u++) dd[u] = w.D[min(k0 + lane + 64 * u, kp->B - 1)];
 #pragma unroll
       for (int u = 0; u < ROUNDS; u++) {
         const int k = k0 + lane + 64 * u;
