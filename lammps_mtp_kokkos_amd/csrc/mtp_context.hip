@@ -503,6 +503,8 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     blob.resize((blob.size() + 15) / 16 * 16, 0);
     c->blob_bytes_norows = (int) blob.size();
     bb.off_rows = put(rows8.data(), rows8.size() * sizeof(MtpRow8));
+    bb.off_leaf_cf = put(pot->leaf_cf.data(), pot->leaf_cf.size() * sizeof(double));
+    bb.off_leaf_cb = pot->leaf_cb == pot->leaf_cf ? bb.off_leaf_cf : put(pot->leaf_cb.data(), pot->leaf_cb.size() * sizeof(double));
     blob.resize((blob.size() + 15) / 16 * 16, 0);
     c->blob_bytes_rows = (int) blob.size();
     bb.blob_bytes = c->blob_bytes_norows;   // plan() decides per launch plan

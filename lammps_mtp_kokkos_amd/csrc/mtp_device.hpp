@@ -52,6 +52,7 @@ struct MtpDevParams {
   int nfb;                 // number of those blocks
   int off_smu;             // int[nslot] radial function index mu of each slot
   int off_coef;            // int2[B] scatter targets of each basic's adjoint: {tx | ty << 16, tz | fa << 16 | fb << 20 | fc << 24}
+  int off_leaf_cf, off_leaf_cb;   // double[leaf rows], behind the rows (same prefix): one array when the two agree
   int rows_in_lds;
   int tgt_in_lds;          // the scatter targets (off_coef) are in the blob prefix of this launch; else read g_tgt (HBM / L2)
   const int *g_tgt;

@@ -155,6 +155,6 @@ template <> struct Butterfly<1> {
 struct BlockTables {   // views into the workgroup-shared head of LDS
   const MtpRow8 *rows;
   const int *level, *slot, *seed_idx, *map, *pack, *coef, *smu, *fwd, *seg_fwd, *seg_bwd;
-  const double *radial, *seed_val, *lin;
+  const double *radial, *seed_val, *lin, *leaf_cf, *leaf_cb;
 };
 

@@ -378,61 +378,120 @@ __device__ __forceinline__ void products_backward(const MtpRow8 *rows, const int
 // moments have no LDS slot in force calls.  Forward: the row's product goes straight into the site energy,
 // e += cf M[a0] M[a1] with cf = linear coefficient x mult (grade calls also keep M[a3] += mult M[a0] M[a1]: the
 // candidate vector lists the leaves' values).  Reverse: D[a0] += cb M[a1], D[a1] += cb M[a0] with the constant adjoint
-// cb = seed(a3) x mult -- no D[a3] read.  Row per lane as above; the constants come from HBM / L2, lane-contiguous.
-template <int U, bool STORE>
+// cb = seed(a3) x mult -- no D[a3] read.  Row per lane as above; the constants are lane-contiguous like the rows.
+// FAR: rows and constants come from HBM / L2 (wide lane grids, whose rows do not fit in LDS): batches of U rows are
+// requested MTP_LD batches ahead of their use, as in the gather passes; otherwise both sit in the LDS blob.
+#ifndef MTP_LD
+#define MTP_LD 1   // (2: equal, 4: 2 % slower at level 20)
+#endif
+template <int U, bool STORE, bool FAR>
 __device__ __forceinline__ double leaf_forward(const MtpRow8 *rows, const double *cf, int beg, int nit, double *M, int lane)
 {
+  constexpr int D = FAR ? MTP_LD : 1;
   double e = 0.0;
   const MtpRow8 *rp = rows + beg + lane;
   const double *cp = cf + lane;
-  for (int it = 0; it < nit; it += U) {
-    MtpRow8 rw[U];
-    double c[U], v[U];
+  const int nb = (nit + U - 1) / U;
+  MtpRow8 q[D][U];
+  double qc[D][U];
+  auto fetch = [&](int b, MtpRow8 (&r)[U], double (&c)[U]) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const int b = 64 * min(it + u, nit - 1);   // uniform clamp: the tail re-reads the last block
-      rw[u] = rp[b];
-      c[u] = cp[b];
+      const int o = 64 * min(b * U + u, nit - 1);   // uniform clamp: the tail re-reads the last block
+      r[u] = rp[o];
+      c[u] = cp[o];
     }
+  };
+  if (FAR) {
 #pragma unroll
-    for (int u = 0; u < U; u++) v[u] = M[rw[u].lo & 0xffffu] * M[rw[u].lo >> 16];
+    for (int d = 0; d < D; d++)
+      if (d < nb) fetch(d, q[d], qc[d]);   // uniform
+  }
+  for (int b0 = 0; b0 < nb; b0 += D) {
 #pragma unroll
-    for (int u = 0; u < U; u++)
-      if (it + u < nit) {   // uniform branch
-        e = fma(c[u], v[u], e);
-        if (STORE) lds_add(&M[rw[u].hi & 0xffffu], (double) ((int) rw[u].hi >> 16) * v[u]);
+    for (int d = 0; d < D; d++) {
+      const int b = b0 + d;
+      if (b < nb) {   // uniform
+        MtpRow8 rw[U];
+        double c[U], v[U];
+        if (FAR) {
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            rw[u] = q[d][u];
+            c[u] = qc[d][u];
+          }
+          if (b + D < nb) fetch(b + D, q[d], qc[d]);   // uniform
+        } else {
+          fetch(b, rw, c);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = M[rw[u].lo & 0xffffu] * M[rw[u].lo >> 16];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (b * U + u < nit) {   // uniform branch
+            e = fma(c[u], v[u], e);
+            if (STORE) lds_add(&M[rw[u].hi & 0xffffu], (double) ((int) rw[u].hi >> 16) * v[u]);
+          }
       }
+    }
   }
   if (STORE) wave_fence();
   return e;
 }
 
-template <int U>
+template <int U, bool FAR>
 __device__ __forceinline__ void leaf_backward(const MtpRow8 *rows, const double *cb, int beg, int nit, const double *M,
-                                              double *D, int lane)
+                                              double *D_, int lane)
 {
+  constexpr int D = FAR ? MTP_LD : 1;
   const MtpRow8 *rp = rows + beg + lane;
   const double *cp = cb + lane;
-  for (int it = 0; it < nit; it += U) {
-    MtpRow8 rw[U];
-    double c[U], m0[U], m1[U];
+  const int nb = (nit + U - 1) / U;
+  MtpRow8 q[D][U];
+  double qc[D][U];
+  auto fetch = [&](int b, MtpRow8 (&r)[U], double (&c)[U]) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const int b = 64 * min(it + u, nit - 1);
-      rw[u] = rp[b];
-      c[u] = cp[b];
+      const int o = 64 * min(b * U + u, nit - 1);
+      r[u] = rp[o];
+      c[u] = cp[o];
     }
+  };
+  if (FAR) {
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      m0[u] = M[rw[u].lo & 0xffffu];
-      m1[u] = M[rw[u].lo >> 16];
-    }
+    for (int d = 0; d < D; d++)
+      if (d < nb) fetch(d, q[d], qc[d]);
+  }
+  for (int b0 = 0; b0 < nb; b0 += D) {
 #pragma unroll
-    for (int u = 0; u < U; u++)
-      if (it + u < nit) {
-        lds_add(&D[rw[u].lo >> 16], c[u] * m0[u]);
-        lds_add(&D[rw[u].lo & 0xffffu], c[u] * m1[u]);
+    for (int d = 0; d < D; d++) {
+      const int b = b0 + d;
+      if (b < nb) {
+        MtpRow8 rw[U];
+        double c[U], m0[U], m1[U];
+        if (FAR) {
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            rw[u] = q[d][u];
+            c[u] = qc[d][u];
+          }
+          if (b + D < nb) fetch(b + D, q[d], qc[d]);
+        } else {
+          fetch(b, rw, c);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          m0[u] = M[rw[u].lo & 0xffffu];
+          m1[u] = M[rw[u].lo >> 16];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (b * U + u < nit) {
+            lds_add(&D_[rw[u].lo >> 16], c[u] * m0[u]);
+            lds_add(&D_[rw[u].lo & 0xffffu], c[u] * m1[u]);
+          }
       }
+    }
   }
   wave_fence();
 }
@@ -441,7 +500,8 @@ __device__ __forceinline__ void leaf_backward(const MtpRow8 *rows, const double 
 // acc = sum_u mult_u X[o0_u] Y[o1_u] over its CS operations, then ONE atomic add T[tgt] += acc.  Forward: X = Y = T =
 // moments (rows of one target); reverse: X = adjoints, Y = moments, T = adjoints (the terms of one destination), so a
 // reverse level issues one ds_add_f64 per CS terms instead of two per row.  Operations (8 bytes, lane-contiguous) come
-// from HBM / L2; those of the next trip are requested before the current trip's operands are read.
+// from HBM / L2; those of the next trip are requested before the current trip's operands are read (a ring of 2, 4 or
+// 8 trips in flight was measured slower at level 20: 1.46 / 1.50 / 1.60 against 1.40 ms).
 template <int CS>
 __device__ __forceinline__ void gather_groups(const MtpRow8 *rp, int ngroups, const double *X, const double *Y, double *T)
 {
@@ -643,6 +703,8 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
   bt.coef = reinterpret_cast<const int *>(sh + kp->off_coef);
   bt.smu = reinterpret_cast<const int *>(sh + kp->off_smu);
   bt.fwd = reinterpret_cast<const int *>(sh + kp->off_fwd);
+  bt.leaf_cf = reinterpret_cast<const double *>(sh + kp->off_leaf_cf);   // (behind the rows: valid when rows_in_lds)
+  bt.leaf_cb = reinterpret_cast<const double *>(sh + kp->off_leaf_cb);
   const bool rows_lds = kp->rows_in_lds != 0;
 
   const int lane = threadIdx.x & 63;
@@ -897,8 +959,8 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     const int leaf_beg = __builtin_amdgcn_readfirstlane(bt.level[kp->nlevels]);
     const int leaf_nit = (__builtin_amdgcn_readfirstlane(bt.level[kp->nlevels + 1]) - leaf_beg) >> 6;
 #ifndef MTP_EXP_NOPRODUCTS
-    if (rows_lds) e = leaf_forward<MTP_PU, GRADE>(bt.rows, kp->leaf_cf, leaf_beg, leaf_nit, w.M, lane);
-    else e = leaf_forward<MTP_PU, GRADE>(kp->rows, kp->leaf_cf, leaf_beg, leaf_nit, w.M, lane);
+    if (rows_lds) e = leaf_forward<MTP_PU, GRADE, false>(bt.rows, bt.leaf_cf, leaf_beg, leaf_nit, w.M, lane);
+    else e = leaf_forward<MTP_PU, GRADE, true>(kp->rows, kp->leaf_cf, leaf_beg, leaf_nit, w.M, lane);
 #endif
     STAMP(4);   // products forward
     KP_FRESH();
@@ -923,8 +985,8 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     STAMP(5);   // energy + seeds
     KP_FRESH();
 #ifndef MTP_EXP_NOPRODUCTS
-    if (rows_lds) leaf_backward<MTP_PU>(bt.rows, kp->leaf_cb, leaf_beg, leaf_nit, w.M, w.D, lane);
-    else leaf_backward<MTP_PU>(kp->rows, kp->leaf_cb, leaf_beg, leaf_nit, w.M, w.D, lane);
+    if (rows_lds) leaf_backward<MTP_PU, false>(bt.rows, bt.leaf_cb, leaf_beg, leaf_nit, w.M, w.D, lane);
+    else leaf_backward<MTP_PU, true>(kp->rows, kp->leaf_cb, leaf_beg, leaf_nit, w.M, w.D, lane);
     if constexpr (GATHER) {
       gather_pass(kp->prog_bwd, bt.seg_bwd, kp->nlevels, w.D, w.M, w.D, lane);
     } else {

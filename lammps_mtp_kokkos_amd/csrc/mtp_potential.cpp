@@ -682,140 +682,6 @@ int mtp_potential::finalize(std::string &err)
       leaf_cb[r] = c_seed[(size_t) row.a3] * row.mult;
     }
   }
-  // ---- gather programs of the product passes ---------------------------------------------------------------------
-  // The product passes as the kernel runs them (mtp_kernels.hip, gather_pass): per level a list of *chunks*; a chunk
-  // holds up to cs operations acc += mult * X[o0] * Y[o1] that share one target, lane l of a group of 64 lanes runs one
-  // chunk and ends it with ONE atomic add T[tgt] += acc.  Forward pass (pair_mtp.cpp:196-201): X = Y = T = moments,
-  // chunks = the rows of a target.  Reverse pass (:221-233): X = adjoints, Y = moments, T = adjoints, chunks = the
-  // terms D[a3] mult M[other] of one destination moment -- so the reverse pass needs two atomics per FOUR-TO-EIGHT
-  // rows instead of two per row.  The chunk size cs in {1, 2, 4, 8} is chosen per level and pass by modelled LDS cycles
-  // (2 per read, 15 per atomic add, padding included); chunks are dealt to lanes greedily so that the operands of one
-  // wave instruction spread over the LDS banks (reads: 32 lanes over 32 eight-byte banks, adds: 16 lanes over 16).
-  {
-    const int nlev2 = normal_levels;   // (the leaf rows keep the row-per-lane form: no target to share)
-    const int A_st = stored_moment_count;
-    auto build = [&](bool reverse, std::vector<MtpRow> &prog, std::vector<int32_t> &seg) {
-      prog.clear();
-      seg.clear();
-      for (int li = 0; li < nlev2; li++) {
-        const int l = reverse ? nlev2 - 1 - li : li;
-        // operations of the level, keyed by target
-        std::vector<std::vector<MtpRow>> by_tgt((size_t) A);
-        for (int r = level_offset[l]; r < level_offset[l + 1]; r++) {
-          const MtpRow &row = rows_by_level[(size_t) r];
-          if (row.mult == 0) continue;   // neutral padding rows of the old layout
-          if (!reverse) {
-            by_tgt[(size_t) row.a3].push_back(row);
-          } else if (row.a0 == row.a1 && 2 * row.mult <= 32767 && 2 * row.mult >= -32768) {
-            by_tgt[(size_t) row.a0].push_back(MtpRow{row.a3, row.a0, 2 * row.mult, row.a0});   // both terms in one
-          } else {
-            by_tgt[(size_t) row.a1].push_back(MtpRow{row.a3, row.a0, row.mult, row.a1});       // D[a1] += D[a3] mult M[a0]
-            by_tgt[(size_t) row.a0].push_back(MtpRow{row.a3, row.a1, row.mult, row.a0});       // D[a0] += D[a3] mult M[a1]
-          }
-        }
-        // chunk size by modelled LDS cycles
-        int best_cs = 1;
-        long long best_cost = -1;
-        for (int cs : {1, 2, 4, 8}) {
-          long long chunks = 0;
-          for (const auto &v : by_tgt) chunks += ((long long) v.size() + cs - 1) / cs;
-          const long long groups = (chunks + 63) / 64, cost = groups * cs * 6 + groups * 15;
-          if (best_cost < 0 || cost < best_cost) {
-            best_cost = cost;
-            best_cs = cs;
-          }
-        }
-        const int cs = best_cs;
-        struct Chunk {
-          int tgt;
-          MtpRow op[8];
-        };
-        std::vector<Chunk> chunks;
-        for (int t = 0; t < A; t++) {
-          const auto &v = by_tgt[(size_t) t];
-          for (size_t b = 0; b < v.size(); b += (size_t) cs) {
-            Chunk c;
-            c.tgt = t;
-            for (int u = 0; u < cs; u++) c.op[u] = b + u < v.size() ? v[b + u] : MtpRow{t, t, 0, t};
-            chunks.push_back(c);
-          }
-        }
-        // longest-first would not matter (all chunks are cs long after padding); keep file order, pad to whole groups
-        const int ngroups = (int) ((chunks.size() + 63) / 64);
-        const int first_block = (int) (prog.size() / 64);
-        std::vector<char> used(chunks.size(), 0);
-        size_t scan_from = 0;
-        for (int g = 0; g < ngroups; g++) {
-          int occx[8][2][32], occy[8][2][32], occt[4][16];
-          for (auto &a : occx)
-            for (auto &b : a)
-              for (int &c : b) c = -1;
-          for (auto &a : occy)
-            for (auto &b : a)
-              for (int &c : b) c = -1;
-          for (auto &a : occt)
-            for (int &c : a) c = -1;
-          std::vector<MtpRow> blk((size_t) 64 * cs);
-          for (int lane = 0; lane < 64; lane++) {
-            const int half = lane >> 5, q16 = lane >> 4;
-            int best = -1, best_rot = 0, bcost = 1 << 30, seen = 0;
-            for (size_t k = scan_from; k < chunks.size() && seen < 128; k++) {
-              if (used[k]) continue;
-              seen++;
-              const Chunk &c = chunks[k];
-              const int tcost = 3 * (occt[q16][c.tgt & 15] >= 0);
-              for (int rot = 0; rot < cs; rot++) {
-                int cost = tcost;
-                for (int u = 0; u < cs; u++) {
-                  const MtpRow &o = c.op[(u + rot) % cs];
-                  const int bx = occx[u][half][o.a0 & 31], by = occy[u][half][o.a1 & 31];
-                  cost += (bx >= 0 && bx != o.a0) + (by >= 0 && by != o.a1);
-                }
-                if (cost < bcost) {
-                  bcost = cost;
-                  best = (int) k;
-                  best_rot = rot;
-                }
-                if (cost == 0) break;
-              }
-              if (bcost == 0) break;
-            }
-            Chunk c;
-            if (best >= 0) {
-              c = chunks[(size_t) best];
-              used[(size_t) best] = 1;
-              while (scan_from < chunks.size() && used[scan_from]) scan_from++;
-            } else {   // padding chunk: adds 0.0 to a moment whose add bank is still free in this 16-lane group
-              int t = 0;
-              for (int m = 0; m < A_st; m++)
-                if (occt[q16][m & 15] < 0) {
-                  t = m;
-                  break;
-                }
-              c.tgt = t;
-              for (int u = 0; u < cs; u++) c.op[u] = MtpRow{t, t, 0, t};
-              best_rot = 0;
-            }
-            occt[q16][c.tgt & 15] = c.tgt;
-            for (int u = 0; u < cs; u++) {
-              MtpRow o = c.op[(u + best_rot) % cs];
-              o.a3 = c.tgt;
-              occx[u][half][o.a0 & 31] = o.a0;
-              occy[u][half][o.a1 & 31] = o.a1;
-              blk[(size_t) u * 64 + lane] = o;
-            }
-          }
-          prog.insert(prog.end(), blk.begin(), blk.end());
-        }
-        seg.push_back(first_block);
-        seg.push_back(ngroups);
-        seg.push_back(cs);
-        seg.push_back(0);
-      }
-    };
-    build(false, prog_fwd, seg_fwd);
-    build(true, prog_bwd, seg_bwd);
-  }
   mapping_lds.resize((size_t) S);
   for (int i = 0; i < S; i++) mapping_lds[i] = moment_perm[alpha_moment_mapping[i]];
 
@@ -948,6 +814,312 @@ int mtp_potential::finalize(std::string &err)
       }
       if (hits[t] == 0) coef_dense = 0;
     }
+  }
+  // ---- gather programs of the product passes ---------------------------------------------------------------------
+  // The product passes as the kernel runs them (mtp_kernels.hip, gather_pass): per level a list of *chunks*; a chunk
+  // holds up to cs operations acc += mult * X[o0] * Y[o1] that share one target, lane l of a group of 64 lanes runs one
+  // chunk and ends it with ONE atomic add T[tgt] += acc.  Forward pass (pair_mtp.cpp:196-201): X = Y = T = moments,
+  // chunks = the rows of a target.  Reverse pass (:221-233): X = adjoints, Y = moments, T = adjoints, chunks = the
+  // terms D[a3] mult M[other] of one destination moment -- so the reverse pass needs two atomics per FOUR-TO-EIGHT
+  // rows instead of two per row.  The chunk size cs in {1, 2, 4, 8} is chosen per level and pass by modelled LDS cycles
+  // (2 per read, 15 per atomic add, padding included); chunks are dealt to lanes greedily so that the operands of one
+  // wave instruction spread over the LDS banks (reads: 32 lanes over 32 eight-byte banks, adds: 16 lanes over 16).
+  {
+    const int nlev2 = normal_levels;   // (the leaf rows keep the row-per-lane form: no target to share)
+    const int A_st = stored_moment_count;
+    // Local search on top of the greedy deal (deterministic, fixed-seed LCG): swap the chunks of two lanes of the level,
+    // or two operations inside a chunk (their sum does not depend on the order), whenever the modelled extra cycles --
+    // per wave instruction and 32-lane half the largest number of distinct addresses on one read bank, per 16-lane
+    // group the largest number of adds on one bank -- do not grow.  Padding operations (mult 0) are wildcards: they
+    // end up on an address another lane of their half reads anyway (a broadcast).  Measured on the level-20 programs:
+    // average bank load of the reads 2.1 -> 1.3.
+    auto refine = [&](std::vector<MtpRow> &prog, size_t base, int G, int cs) {
+      // (the kernel runs the programs in its 64-lane block grids only -- more than 32 head x tail blocks --, unless
+      // it was built with -DMTP_GATHER_ALL; MTP_REFINE_PROGRAMS=0 / 1 overrides)
+      bool wanted = fwd_block_count > 32;
+      if (const char *e = std::getenv("MTP_REFINE_PROGRAMS")) wanted = std::atoi(e) != 0;
+      if (G * 64 < 2 || !wanted) return;
+      auto op = [&](int g, int u, int lane) -> MtpRow & { return prog[base + ((size_t) g * cs + u) * 64 + lane]; };
+      int hot = 0;   // a lane on the most loaded bank of the last read_cost call
+      auto read_cost = [&](int g, int u, int half, int which) {
+        int first[32], extra[32][7], mx = 0;
+        uint8_t n[32] = {0};
+        for (int lane = 32 * half; lane < 32 * half + 32; lane++) {
+          const MtpRow &o = op(g, u, lane);
+          if (o.mult == 0) continue;
+          const int a = which ? o.a1 : o.a0, b = a & 31;
+          bool dup = false;
+          if (n[b] > 0) {
+            dup = first[b] == a;
+            for (int k = 0; k + 1 < n[b] && k < 7 && !dup; k++) dup = extra[b][k] == a;
+          }
+          if (!dup) {
+            if (n[b] == 0) first[b] = a;
+            else if (n[b] - 1 < 7) extra[b][n[b] - 1] = a;
+            n[b]++;
+            if (n[b] > mx) {
+              mx = n[b];
+              hot = lane;
+            }
+          }
+        }
+        return mx > 1 ? mx - 1 : 0;
+      };
+      auto real_chunk = [&](int g, int lane) {
+        for (int u = 0; u < cs; u++)
+          if (op(g, u, lane).mult != 0) return true;
+        return false;
+      };
+      auto add_cost = [&](int g, int q) {
+        uint8_t h[16] = {0};
+        int mx = 0;
+        for (int lane = 16 * q; lane < 16 * q + 16; lane++)
+          if (real_chunk(g, lane) && ++h[op(g, 0, lane).a3 & 15] > mx) {
+            mx = h[op(g, 0, lane).a3 & 15];
+            hot = lane;
+          }
+        return mx > 1 ? 2 * (mx - 1) : 0;
+      };
+      std::vector<int> rc((size_t) G * cs * 4), ac((size_t) G * 4);
+      for (int g = 0; g < G; g++) {
+        for (int u = 0; u < cs; u++)
+          for (int hw = 0; hw < 4; hw++) rc[((size_t) g * cs + u) * 4 + hw] = read_cost(g, u, hw >> 1, hw & 1);
+        for (int q = 0; q < 4; q++) ac[(size_t) g * 4 + q] = add_cost(g, q);
+      }
+      uint64_t rng = 0xD1B54A32D192ED03ull;
+      auto next = [&]() {
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        return (uint32_t) (rng >> 33);
+      };
+      const long long trials = std::min<long long>(300ll * G * 64, 300000ll);
+      for (long long t = 0; t < trials; t++) {
+        // start from a read (or, one time in four, an add) that has a conflict: a lane on its most loaded bank moves
+        const int g0 = (int) (next() % (uint32_t) G), u0 = (int) (next() % (uint32_t) cs), hw0 = (int) (next() & 3);
+        const bool from_add = (next() & 3) == 0;
+        if (from_add) {
+          if (ac[(size_t) g0 * 4 + hw0] == 0) continue;
+          (void) add_cost(g0, hw0);
+        } else {
+          if (rc[((size_t) g0 * cs + u0) * 4 + hw0] == 0) continue;
+          (void) read_cost(g0, u0, hw0 >> 1, hw0 & 1);
+        }
+        const int lane0 = hot;
+        if (!from_add && cs > 1 && (next() & 1) == 0) {   // two operations of one chunk
+          const int g = g0, lane = lane0, half = lane >> 5;
+          const int u1 = u0, u2 = (int) (next() % (uint32_t) cs);
+          if (u1 == u2) continue;
+          int before = 0, after = 0;
+          for (int w = 0; w < 2; w++) before += rc[((size_t) g * cs + u1) * 4 + 2 * half + w] + rc[((size_t) g * cs + u2) * 4 + 2 * half + w];
+          std::swap(op(g, u1, lane), op(g, u2, lane));
+          int nc[4];
+          for (int w = 0; w < 2; w++) {
+            nc[w] = read_cost(g, u1, half, w);
+            nc[2 + w] = read_cost(g, u2, half, w);
+            after += nc[w] + nc[2 + w];
+          }
+          if (after > before) {
+            std::swap(op(g, u1, lane), op(g, u2, lane));
+            continue;
+          }
+          for (int w = 0; w < 2; w++) {
+            rc[((size_t) g * cs + u1) * 4 + 2 * half + w] = nc[w];
+            rc[((size_t) g * cs + u2) * 4 + 2 * half + w] = nc[2 + w];
+          }
+        } else {   // the chunks of two lanes
+          const int g1 = g0, l1 = lane0;
+          const int g2 = (int) (next() % (uint32_t) G), l2 = (int) (next() & 63);
+          const int h1 = l1 >> 5, h2 = l2 >> 5, q1 = l1 >> 4, q2 = l2 >> 4;
+          if (g1 == g2 && q1 == q2) continue;   // same add group, hence same read half: nothing changes
+          const bool same_half = g1 == g2 && h1 == h2;
+          int before = ac[(size_t) g1 * 4 + q1] + ac[(size_t) g2 * 4 + q2], after = 0;
+          for (int u = 0; u < cs; u++)
+            for (int w = 0; w < 2; w++) {
+              before += rc[((size_t) g1 * cs + u) * 4 + 2 * h1 + w];
+              if (!same_half) before += rc[((size_t) g2 * cs + u) * 4 + 2 * h2 + w];
+            }
+          for (int u = 0; u < cs; u++) std::swap(op(g1, u, l1), op(g2, u, l2));
+          int n1[16], n2[16];
+          for (int u = 0; u < cs; u++)
+            for (int w = 0; w < 2; w++) {
+              n1[2 * u + w] = read_cost(g1, u, h1, w);
+              after += n1[2 * u + w];
+              if (!same_half) {
+                n2[2 * u + w] = read_cost(g2, u, h2, w);
+                after += n2[2 * u + w];
+              }
+            }
+          const int a1 = add_cost(g1, q1), a2 = add_cost(g2, q2);
+          after += a1 + a2;
+          if (after > before) {
+            for (int u = 0; u < cs; u++) std::swap(op(g1, u, l1), op(g2, u, l2));
+            continue;
+          }
+          for (int u = 0; u < cs; u++)
+            for (int w = 0; w < 2; w++) {
+              rc[((size_t) g1 * cs + u) * 4 + 2 * h1 + w] = n1[2 * u + w];
+              if (!same_half) rc[((size_t) g2 * cs + u) * 4 + 2 * h2 + w] = n2[2 * u + w];
+            }
+          ac[(size_t) g1 * 4 + q1] = a1;
+          ac[(size_t) g2 * 4 + q2] = a2;
+        }
+      }
+      // wildcards: read what another lane of the half reads (broadcast); padding chunks add 0.0 on a free add bank
+      for (int g = 0; g < G; g++) {
+        for (int u = 0; u < cs; u++)
+          for (int half = 0; half < 2; half++) {
+            int a0 = 0, a1 = 0;
+            for (int lane = 32 * half; lane < 32 * half + 32; lane++)
+              if (op(g, u, lane).mult != 0) {
+                a0 = op(g, u, lane).a0;
+                a1 = op(g, u, lane).a1;
+                break;
+              }
+            for (int lane = 32 * half; lane < 32 * half + 32; lane++)
+              if (op(g, u, lane).mult == 0) {
+                op(g, u, lane).a0 = a0;
+                op(g, u, lane).a1 = a1;
+              }
+          }
+        for (int q = 0; q < 4; q++) {
+          bool busy[16] = {false};
+          for (int lane = 16 * q; lane < 16 * q + 16; lane++)
+            if (real_chunk(g, lane)) busy[op(g, 0, lane).a3 & 15] = true;
+          for (int lane = 16 * q; lane < 16 * q + 16; lane++) {
+            if (real_chunk(g, lane)) continue;
+            int t = op(g, 0, lane).a3;
+            for (int m = 0; m < A_st; m++)
+              if (!busy[m & 15]) {
+                t = m;
+                break;
+              }
+            busy[t & 15] = true;
+            for (int u = 0; u < cs; u++) op(g, u, lane).a3 = t;
+          }
+        }
+      }
+    };
+    auto build = [&](bool reverse, std::vector<MtpRow> &prog, std::vector<int32_t> &seg) {
+      prog.clear();
+      seg.clear();
+      for (int li = 0; li < nlev2; li++) {
+        const int l = reverse ? nlev2 - 1 - li : li;
+        // operations of the level, keyed by target
+        std::vector<std::vector<MtpRow>> by_tgt((size_t) A);
+        for (int r = level_offset[l]; r < level_offset[l + 1]; r++) {
+          const MtpRow &row = rows_by_level[(size_t) r];
+          if (row.mult == 0) continue;   // neutral padding rows of the old layout
+          if (!reverse) {
+            by_tgt[(size_t) row.a3].push_back(row);
+          } else if (row.a0 == row.a1 && 2 * row.mult <= 32767 && 2 * row.mult >= -32768) {
+            by_tgt[(size_t) row.a0].push_back(MtpRow{row.a3, row.a0, 2 * row.mult, row.a0});   // both terms in one
+          } else {
+            by_tgt[(size_t) row.a1].push_back(MtpRow{row.a3, row.a0, row.mult, row.a1});       // D[a1] += D[a3] mult M[a0]
+            by_tgt[(size_t) row.a0].push_back(MtpRow{row.a3, row.a1, row.mult, row.a0});       // D[a0] += D[a3] mult M[a1]
+          }
+        }
+        // chunk size by modelled LDS cycles
+        int best_cs = 1;
+        long long best_cost = -1;
+        for (int cs : {1, 2, 4, 8}) {
+          long long chunks = 0;
+          for (const auto &v : by_tgt) chunks += ((long long) v.size() + cs - 1) / cs;
+          const long long groups = (chunks + 63) / 64, cost = groups * cs * 6 + groups * 15;
+          if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best_cs = cs;
+          }
+        }
+        const int cs = best_cs;
+        struct Chunk {
+          int tgt;
+          MtpRow op[8];
+        };
+        std::vector<Chunk> chunks;
+        for (int t = 0; t < A; t++) {
+          const auto &v = by_tgt[(size_t) t];
+          for (size_t b = 0; b < v.size(); b += (size_t) cs) {
+            Chunk c;
+            c.tgt = t;
+            for (int u = 0; u < cs; u++) c.op[u] = b + u < v.size() ? v[b + u] : MtpRow{t, t, 0, t};
+            chunks.push_back(c);
+          }
+        }
+        // longest-first would not matter (all chunks are cs long after padding); keep file order, pad to whole groups
+        const int ngroups = (int) ((chunks.size() + 63) / 64);
+        const int first_block = (int) (prog.size() / 64);
+        std::vector<char> used(chunks.size(), 0);
+        size_t scan_from = 0;
+        for (int g = 0; g < ngroups; g++) {
+          int occx[8][2][32], occy[8][2][32], occt[4][16];
+          for (auto &a : occx)
+            for (auto &b : a)
+              for (int &c : b) c = -1;
+          for (auto &a : occy)
+            for (auto &b : a)
+              for (int &c : b) c = -1;
+          for (auto &a : occt)
+            for (int &c : a) c = -1;
+          std::vector<MtpRow> blk((size_t) 64 * cs);
+          for (int lane = 0; lane < 64; lane++) {
+            const int half = lane >> 5, q16 = lane >> 4;
+            int best = -1, best_rot = 0, bcost = 1 << 30, seen = 0;
+            for (size_t k = scan_from; k < chunks.size() && seen < 128; k++) {
+              if (used[k]) continue;
+              seen++;
+              const Chunk &c = chunks[k];
+              const int tcost = 3 * (occt[q16][c.tgt & 15] >= 0);
+              for (int rot = 0; rot < cs; rot++) {
+                int cost = tcost;
+                for (int u = 0; u < cs; u++) {
+                  const MtpRow &o = c.op[(u + rot) % cs];
+                  const int bx = occx[u][half][o.a0 & 31], by = occy[u][half][o.a1 & 31];
+                  cost += (bx >= 0 && bx != o.a0) + (by >= 0 && by != o.a1);
+                }
+                if (cost < bcost) {
+                  bcost = cost;
+                  best = (int) k;
+                  best_rot = rot;
+                }
+                if (cost == 0) break;
+              }
+              if (bcost == 0) break;
+            }
+            Chunk c;
+            if (best >= 0) {
+              c = chunks[(size_t) best];
+              used[(size_t) best] = 1;
+              while (scan_from < chunks.size() && used[scan_from]) scan_from++;
+            } else {   // padding chunk: adds 0.0 to a moment whose add bank is still free in this 16-lane group
+              int t = 0;
+              for (int m = 0; m < A_st; m++)
+                if (occt[q16][m & 15] < 0) {
+                  t = m;
+                  break;
+                }
+              c.tgt = t;
+              for (int u = 0; u < cs; u++) c.op[u] = MtpRow{t, t, 0, t};
+              best_rot = 0;
+            }
+            occt[q16][c.tgt & 15] = c.tgt;
+            for (int u = 0; u < cs; u++) {
+              MtpRow o = c.op[(u + best_rot) % cs];
+              o.a3 = c.tgt;
+              occx[u][half][o.a0 & 31] = o.a0;
+              occy[u][half][o.a1 & 31] = o.a1;
+              blk[(size_t) u * 64 + lane] = o;
+            }
+          }
+          prog.insert(prog.end(), blk.begin(), blk.end());
+        }
+        refine(prog, (size_t) first_block * 64, ngroups, cs);
+        seg.push_back(first_block);
+        seg.push_back(ngroups);
+        seg.push_back(cs);
+        seg.push_back(0);
+      }
+    };
+    build(false, prog_fwd, seg_fwd);
+    build(true, prog_bwd, seg_bwd);
   }
   return MTP_OK;
 }
