@@ -129,10 +129,9 @@ void mtp_context::plan()
   (void) mtp_pick_shape(p.alpha_index_basic_count, &KL, &KB);
   const int cap = std::max(64, (max_numneigh + 31) / 32 * 32);
   const size_t LDS = 160 * 1024;
-  size_t blob = (size_t) blob_bytes_core;   // the shape is planned with the smallest prefix; what still fits is added then
   const int nt = 32;
-  for (int which : {0, 2}) {   // [0] fused force kernel, [2] its grade instantiation
-    LaunchPlan &L = lp[which];
+  // One plan for a given table-blob prefix; returns the wavefronts per CU it reaches (0: does not fit).
+  auto plan_one = [&](int which, size_t blob, LaunchPlan &L) -> int {
     L.tab_rows = 2 * p.slot_count + 3 * P;
     L.g_doubles = 0;
     // leaf moments have no LDS slot in force calls; grade calls keep their values (candidate vector), not their adjoints
@@ -235,7 +234,7 @@ void mtp_context::plan()
         w3 = vw3;
       }
     }
-    if (!pick) throw HipFail{hipErrorInvalidValue, "potential + neighbour list exceed one CU's LDS"};
+    if (!pick) return 0;
     L.layout = *pick;
     L.rebuild = pick->mode == 2;
     L.wps = wps;
@@ -256,7 +255,7 @@ void mtp_context::plan()
           best_w = w;
         }
       }
-      if (best == 0) throw HipFail{hipErrorInvalidValue, "potential + neighbour list exceed one CU's LDS"};
+      if (best == 0) return 0;
       if (fine)   // ... but no wider than needed to give every atom its own wavefront
         for (int w = 1; w < best_w; w++)
           if ((long long) num_cus * waves2(w, wb) >= inum) {
@@ -281,6 +280,21 @@ void mtp_context::plan()
     L.lds_bytes = (size_t) L.blob_bytes + wb * best_w;
     const int need = (inum + best_w - 1) / best_w;
     L.grid = std::max(1, std::min(need, num_cus * blocks_per_cu));
+    return best;
+  };
+  // The shape is planned against each prefix of the table blob, longest first: a shorter prefix (tables read from
+  // HBM / L2 instead) is taken only when it buys wavefronts per CU (level 20: 8 instead of 7 with the core prefix).
+  for (int which : {0, 2}) {   // [0] fused force kernel, [2] its grade instantiation
+    int best_waves = 0;
+    for (int bytes : {blob_bytes_rows, blob_bytes_norows, blob_bytes_tgt, blob_bytes_core}) {
+      LaunchPlan L;
+      const int v = plan_one(which, (size_t) bytes, L);
+      if (v > best_waves) {
+        best_waves = v;
+        lp[which] = L;
+      }
+    }
+    if (best_waves == 0) throw HipFail{hipErrorInvalidValue, "potential + neighbour list exceed one CU's LDS"};
   }
   {   // [1] candidate-vector kernel of grade calls: small table (r^-nu, Q_ri, powers), 8 wavefronts per workgroup
     LaunchPlan &L = lp[1];

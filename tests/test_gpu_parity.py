@@ -82,6 +82,23 @@ def test_other_levels_and_species(tmp_path, level, species):
     _compare(_pot(tmp_path, level, species, "p.mtp"), _system((3, 3, 3), species=species))
 
 
+@pytest.mark.parametrize("no_leaf", [False, True])
+def test_schedule_corner_cases_late_writer_and_shared_scalar(tmp_path, monkeypatch, no_leaf):
+    """The product schedule on a table real generators do not emit (tests/_mutate.py): a row that adds to a factor
+    AFTER never-read scalars used it, and two coefficients on one never-read scalar -- against the oracle's file-order
+    loops (pair_mtp.cpp:196-233), with the leaf-row treatment on and off (MTP_NO_LEAF, read when the file is loaded)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _mutate import mutate_mtp
+    if no_leaf:
+        monkeypatch.setenv("MTP_NO_LEAF", "1")
+    for src, level, species in ((os.path.join(POT, "W_L16.mtp"), 16, 1), (_pot(tmp_path, 18, 2, "l18.mtp"), 18, 2)):
+        dst = str(tmp_path / ("mut%d.mtp" % level))
+        info = mutate_mtp(src, dst)
+        assert info["leaves"] > 0
+        _compare(dst, _system((3, 3, 3), species))
+
+
 def test_many_in_cutoff_neighbours_multi_tile():
     """compressed lattice: 58 neighbours inside 5 A -> more than one 32-neighbour LDS tile"""
     s = _system((4, 4, 4), a=2.6, list_cutoff=6.0)

@@ -37,6 +37,28 @@ def test_committed_potentials_parse_clean_under_sanitizers(exe, fname, sel):
     assert float(out.split()[8]) < 1e-12, out
 
 
+@pytest.mark.parametrize("fname", ["W_L16.mtp", "WRe_L10_cfg.almtp"])
+def test_schedule_corner_cases_follow_the_in_order_semantics(exe, tmp_path, fname):
+    """A late writer of a factor of never-read scalars (their rows may then not be deferred as leaf rows) and two
+    coefficients on one never-read scalar: the driver replays both forms of the native schedule, leaf rows included,
+    against the file-order loops of pair_mtp.cpp:196-233."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _mutate import mutate_mtp
+    src = os.path.join(POT, fname)
+    text_only = str(tmp_path / "plain.mtp")
+    data = open(src, "rb").read()
+    open(text_only, "wb").write(data[: data.index(b"#MVS_v1.1")] if b"#MVS_v1.1" in data else data)
+    dst = str(tmp_path / "mutated.mtp")
+    info = mutate_mtp(text_only, dst)
+    assert info["leaves"] > 0
+    base, out = _run(exe, text_only, 0), _run(exe, dst, 0)
+    assert base.startswith("OK ") and out.startswith("OK "), (base, out)
+    assert float(out.split()[8]) < 1e-12, out
+    # the late writer costs leaves their special treatment: the checksum (which includes the stored-moment count) moves
+    assert out.split()[7] != base.split()[7]
+
+
 def test_truncated_and_corrupted_files_fail_cleanly(exe, tmp_path):
     data = open(os.path.join(POT, "W_L16_nbh.almtp"), "rb").read()
     text_end = data.index(b"#MVS_v1.1")
