@@ -85,6 +85,9 @@ def main():
                     help="w16: BASELINE configs[1] (default); small2k: configs[2]; wre20: level-20 W-Re shard of "
                          "configs[3]; grades: configs[4] (MaxVol neighbourhood grades every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="single GPU: capture one step (zero f, force call, tally fold) in a HIP graph and time its replays "
+                         "-- for launch-bound sizes (a caller like LAMMPS can do the same around mtp_compute_device)")
     ap.add_argument("--no-whole-step", action="store_true", help="skip the device-resident MD loop (whole-step time)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -222,11 +225,21 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.synchronize(stream)
+    run_step = step
+    if args.graph and world == 1 and not decomposed:
+        # the library's device path only launches kernels on the caller's stream, so a step can be captured and replayed
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=torch.cuda.current_stream(dev)):
+            step()
+        run_step = graph.replay
+        for _ in range(3):
+            run_step()
+        ctx.synchronize(stream)
     ev.zero_()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run_step()
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -399,7 +412,7 @@ def main():
                            % (halo_info["nranks"], halo_info["rccl_version"]) if halo_info else "torch all-to-all halo (%s)%s" % (
                                backend, "; " + halo_note if halo_note else ""),
                            ", rows interior|boundary|interior = %d|%d|%d overlap both exchanges" % (n_a, n_b, n_c) if use_rows else ""))
-                       if decomposed else "single GPU",
+                       if decomposed else ("single GPU, step replayed from a HIP graph" if run_step is not step else "single GPU"),
                        "atoms_rank0": plan.nlocal, "ghosts_rank0": plan.nghost, "list_entries_rank0": int(plan.first[-1]),
                        "in_cutoff_pairs_rank0": jc_total, "launch": info,
                        "device_list_build_ms": list_build_ms},

@@ -248,6 +248,45 @@ def test_device_pointer_path_matches_host_path():
     _close(ea.cpu().numpy(), want["eatom"], "device eatom")
 
 
+def test_step_is_capturable_in_a_hip_graph():
+    """The device path only launches kernels on the caller's stream (no allocation, copy or synchronisation after the
+    first call), so a caller can capture zero + force call + tally fold in a HIP graph; the replays must reproduce the
+    oracle.  (Measured on MI355X / ROCm 7.2: replaying is slower than launching -- bench.py --graph --, so the bench
+    does not use it by default.)"""
+    import torch
+    s = _system((4, 4, 4))
+    path = os.path.join(POT, "W_L16.mtp")
+    pot = capi.Potential(path)
+    ctx = capi.Context(pot, 0)
+    dev = torch.device("cuda:0")
+    il, fi, ne = (torch.from_numpy(a).to(dev) for a in (s.ilist, s.first, s.neigh))
+    ctx.set_neighbors_device(il, fi, ne, s.nall, int(np.diff(s.first).max()))
+    x = torch.from_numpy(s.x).to(dev)
+    ty = torch.from_numpy(s.types).to(dev)
+    f = torch.zeros((s.nall, 3), dtype=torch.float64, device=dev)
+    ev = torch.zeros(8, dtype=torch.float64, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+
+    def step(st):
+        capi.zero_async(f, st)
+        ctx.compute_device(x, ty, f, eflag=1, vflag=1, ev_t=ev, stream=st)
+
+    with torch.cuda.stream(side):
+        step(side.cuda_stream)                       # first call: buffers, kernel attributes
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            step(side.cuda_stream)
+        ev.zero_()
+        for _ in range(3):
+            graph.replay()
+        side.synchronize()
+    want = _oracle(path).compute(s.x, s.types, s.ilist, s.first, s.neigh)
+    _close(f.cpu().numpy(), want["f"], "forces of the replayed step")
+    assert abs(float(ev[0].item()) / 3 - want["energy"]) <= 1e-10 * max(1.0, abs(want["energy"]))
+
+
 def test_understated_max_numneigh_is_reported_not_overrun():
     """mtp_set_neighbors_device sizes an LDS array from the caller's max_numneigh; a row with more in-cutoff
     neighbours than that must end in MTP_ERR_LIMIT, not in an LDS overrun."""
