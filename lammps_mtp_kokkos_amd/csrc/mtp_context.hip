@@ -745,9 +745,9 @@ int mtp_build_neighbors_device(mtp_context *c, void *stream, const double *d_x, 
   }
   try {
     const size_t scan_n = (size_t) std::max<long long>(ncell, inum) + 1;
-    const size_t cub_bytes = mtp_neighbor_scan_bytes((int) scan_n);
+    const size_t cub_bytes = mtp_neighbor_scan_bytes((int) scan_n, nall);
     c->d_nb_tmp.reserve(std::max<size_t>(cub_bytes, 16));
-    c->d_nb_scratch.reserve((size_t) 2 * nall + 3 * (size_t) ncell + 2 + (size_t) inum + 1);
+    c->d_nb_scratch.reserve((size_t) 4 * nall + 2 * (size_t) ncell + 2 + (size_t) inum + 1);
     c->d_nb_info.reserve(2);
     c->d_nb_xs.reserve((size_t) 3 * std::max(nall, 1));
     c->d_ilist.reserve((size_t) std::max(inum, 1));

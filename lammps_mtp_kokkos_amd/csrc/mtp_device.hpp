@@ -128,4 +128,4 @@ hipError_t mtp_launch_colsum_kernel(const double *cvec, int cpad, int C, int inu
 hipError_t mtp_launch_neighbor_build(const double *x, int inum, int nall, double cutoff, const double lo[3],
                                      const int ncell3[3], int *scratch, double *xs, void *cub_tmp, size_t cub_bytes, int *ilist,
                                      int *first, int *neigh, int *d_info, hipStream_t st);
-size_t mtp_neighbor_scan_bytes(int n);
+size_t mtp_neighbor_scan_bytes(int n, int nall);
