@@ -974,8 +974,15 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       for (int k = lane; k < kp->Se; k += 64) e += bt.lin[k] * w.M[bt.map[k]];
     else
       for (int k = lane; k < kp->Se; k += 64) e += kp->g_lin[k] * w.M[kp->g_map[k]];
-    if (e_per_atom) e = wave_sum(e) + kp->species_coeffs[itype];
-    else eacc += e + (lane == 0 ? kp->species_coeffs[itype] : 0.0);
+    if (e_per_atom) {
+      e = wave_sum(e) + kp->species_coeffs[itype];
+      if (lane == 9) {   // (lane 9 carries the energy tally; nothing of e stays live into the force phase)
+        if ((kp->eflag & 2) && kp->eatom) kp->eatom[i] = e;
+        if (kp->eflag & 1) tally += e;
+      }
+    } else {
+      eacc += e + (lane == 0 ? kp->species_coeffs[itype] : 0.0);
+    }
     // ---- 4b. adjoints (pair_mtp.cpp:217-233) ----------------------------------------------
     if (MTP_SCALARS_COND)
       for (int k = lane; k < kp->nseed; k += 64) w.D[bt.seed_idx[k]] = bt.seed_val[k];
@@ -1034,8 +1041,6 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     wave_fence();
     STAMP(9);   // coefficient blocks
     KP_FRESH();
-    // per-lane partial sums: force on i (3), virial (6)
-    double fi0 = 0, fi1 = 0, fi2 = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
     {
       const int n = lane & 31, part = lane >> 5;
       unsigned pcol = w.addr(w.tab + n);
@@ -1109,16 +1114,52 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
           if (Fa + Fy == 12345.678) kp->f[3 * j] = Fa;   // keeps the values live
 #endif
         }
-        fi0 += Fx;
-        fi1 += Fy;
-        fi2 += Fz;
+        // ---- totals of this tile over the 64 lanes: force on i (3), virial (6); lane v < 9 ends up with value v.
+        // Per tile, not per atom: nine running sums carried across the tile loop would be live through the whole
+        // force phase (18 VGPRs the 168-VGPR build does not have); atoms with more than 32 neighbours pay one more
+        // reduction per extra tile.
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
         if (kp->vflag && valid) {   // pair_mtp.cpp:257-277 (linear in F: each half tallies its components)
-          v0 -= Fx * x;
-          v1 -= Fy * y;
-          v2 -= Fz * z;
-          v3 -= (Fx * y + Fy * x) * 0.5;
-          v4 -= (Fx * z + Fz * x) * 0.5;
-          v5 -= (Fy * z + Fz * y) * 0.5;
+          v0 = -Fx * x;
+          v1 = -Fy * y;
+          v2 = -Fz * z;
+          v3 = -(Fx * y + Fy * x) * 0.5;
+          v4 = -(Fx * z + Fz * x) * 0.5;
+          v5 = -(Fy * z + Fz * y) * 0.5;
+        }
+        double tot;
+        if (kp->vflag && !v_per_atom) {
+          vacc[0] += v0;
+          vacc[1] += v1;
+          vacc[2] += v2;
+          vacc[3] += v3;
+          vacc[4] += v4;
+          vacc[5] += v5;
+        }
+        if (v_per_atom) {
+          double part16[16] = {Fx, Fy, Fz, v0, v1, v2, v3, v4, v5, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+          Butterfly<16>::run(part16, lane);
+          tot = part16[0];
+        } else {
+          // the mirror partners flip the low lane bits too, so they go first (while every lane still holds
+          // all entries); the quad butterfly then leaves entry (lane & 3) summed over the row
+          double part4[4] = {Fx, Fy, Fz, 0.0};
+#pragma unroll
+          for (int u = 0; u < 3; u++) {
+            part4[u] += partner_f64<8>(part4[u]);
+            part4[u] += partner_f64<4>(part4[u]);
+          }
+          Butterfly<4>::run(part4, lane);
+          tot = part4[0];
+        }
+        tot = pair_sum32(pair_sum16(tot));
+        if (lane < 9) {
+          if (lane < 3) {
+            force_add(kp, 3 * (size_t) i + lane, tot);   // pair_mtp.cpp:248-250
+          } else if (v_per_atom) {
+            tally += tot;
+            if ((kp->vflag & 4) && kp->vatom) kp->vatom[6 * (size_t) i + (lane - 3)] += tot;
+          }
         }
         if (ntiles > 1) wave_fence();
       }
@@ -1132,45 +1173,6 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     }
     STAMP(7);   // forces
     KP_FRESH();
-    // ---- per-atom totals over the 64 lanes: lane v < 9 ends up with value v --------------------
-    double tot;
-    if (kp->vflag && !v_per_atom) {
-      vacc[0] += v0;
-      vacc[1] += v1;
-      vacc[2] += v2;
-      vacc[3] += v3;
-      vacc[4] += v4;
-      vacc[5] += v5;
-    }
-    if (v_per_atom) {
-      double part16[16] = {fi0, fi1, fi2, v0, v1, v2, v3, v4, v5, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      Butterfly<16>::run(part16, lane);
-      tot = part16[0];
-    } else {
-      // the mirror partners flip the low lane bits too, so they go first (while every lane still holds
-      // all entries); the quad butterfly then leaves entry (lane & 3) summed over the row
-      double part4[4] = {fi0, fi1, fi2, 0.0};
-#pragma unroll
-      for (int u = 0; u < 3; u++) {
-        part4[u] += partner_f64<8>(part4[u]);
-        part4[u] += partner_f64<4>(part4[u]);
-      }
-      Butterfly<4>::run(part4, lane);
-      tot = part4[0];
-    }
-    tot = pair_sum32(pair_sum16(tot));
-    if (lane < 9) {
-      if (lane < 3) {
-        force_add(kp, 3 * (size_t) i + lane, tot);   // pair_mtp.cpp:248-250
-      } else if (v_per_atom) {
-        tally += tot;
-        if ((kp->vflag & 4) && kp->vatom) kp->vatom[6 * (size_t) i + (lane - 3)] += tot;
-      }
-    }
-    if (e_per_atom && lane == 9) {
-      if ((kp->eflag & 2) && kp->eatom) kp->eatom[i] = e;
-      if (kp->eflag & 1) tally += e;
-    }
     wave_fence();
     STAMP(8);   // per-atom totals
     KP_FRESH();
