@@ -15,22 +15,7 @@ for wl in w16 small2k wre20 grades; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -- python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-whole-step > $OUT/stats_$wl.json 2> $OUT/stats_$wl.err; echo "stats $wl rc=$?"
   find $OUT/stats_$wl -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} $OUT/${TAG}_${wl}_kernel_stats.csv
 done
-echo '[' > $OUT/${TAG}_self_halo_rehearsal.json
-first=1
-for c in 16 20 25 32; do
-  for mode in plain self; do
-    envs="A=1"; [ $mode = self ] && envs="MTP_BENCH_SELF_HALO=1"
-    env $envs timeout -k 10 200 python bench.py --cells $c --steps 300 --warmup 20 --no-cpu-baseline --no-whole-step > $OUT/sh.json 2> $OUT/sh.err
-    [ $first = 1 ] || echo ',' >> $OUT/${TAG}_self_halo_rehearsal.json
-    first=0
-    python - >> $OUT/${TAG}_self_halo_rehearsal.json <<PY
-import json
-d = json.load(open("$OUT/sh.json"))
-print(json.dumps({"cells": $c, "atoms": d["config"]["atoms"], "mode": "$mode", "ms_per_step": d["ms_per_step"], "kernel_ms_single_launch": d["roofline"]["kernel_ms"], "parallelism": d["config"]["parallelism"]}))
-PY
-  done
-done
-echo ']' >> $OUT/${TAG}_self_halo_rehearsal.json
+bash scripts/gpu_rehearsal.sh $TAG > $OUT/rehearsal.log 2>&1; echo "rehearsal rc=$?"
 MTP_BENCH_BACKEND=gloo timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29733 bench.py --gpus 2 --steps 20 --warmup 3 > $OUT/${TAG}_bench_2rank_gloo_rehearsal.json 2> $OUT/g2.err; echo "2-rank rehearsal rc=$?"
-rm -rf $OUT/stats_*/ $OUT/sh.json
+rm -rf $OUT/stats_*/
 ls -la $OUT | head -40
