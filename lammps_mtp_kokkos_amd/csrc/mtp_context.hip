@@ -105,7 +105,7 @@ struct mtp_context {
     int blob_bytes = 0;   // the blob prefix this plan copies
     size_t lds_bytes = 0;
   } lp[3];   // [0] force calls (wavefront per atom), [1] candidate-vector kernel of grade calls, [2] the fused kernel's
-             // grade instantiation (planned without the 3-per-SIMD build: at 168 VGPRs it spills 52 dwords and is slower)
+             // grade instantiation (its image also holds the leaf moments' values)
   DevBuf<double> d_cvec, d_ainv_pad, d_ainv_tiled, d_dbasic;
   int cpad = 0, dpad = 0;
   // timing
@@ -221,7 +221,10 @@ void mtp_context::plan()
     bool has3 = mtp_wave_kernel_has_wps3(p.fwd_block_count, P);
     if (const char *e = std::getenv("MTP_WPS")) has3 = has3 && std::atoi(e) == 3;   // tuning override: 2 = never, 3 = whenever it fits
     else has3 = has3 && !fine;
-    if (which == 2 && !std::getenv("MTP_GRADE_WPS3")) has3 = false;   // (MTP_GRADE_WPS3=1: timing experiments)
+    // (the grade instantiation spilled 52 dwords at 168 VGPRs and was 2.6 % slower there until the force totals were
+    // reduced per tile: 35 now, and 12 wavefronts per CU make the grade call 8 % faster; MTP_GRADE_WPS3=0 turns it off)
+    if (which == 2)
+      if (const char *e = std::getenv("MTP_GRADE_WPS3")) has3 = has3 && std::atoi(e) != 0;
     const Layout *pick = nullptr;
     int wps = 2, w3 = 0, pick_waves = 0;
     for (const Layout *y : cands) {
