@@ -274,10 +274,12 @@ void mtp_context::plan()
     const int blocks_per_cu = std::max(1, best / best_w);
     // packed times rows in LDS when the chosen shape still fits with them (or when they are tiny)
     auto fits = [&](int bytes) { return (size_t) blocks_per_cu * ((size_t) bytes + best_w * wb) <= LDS; };
-    L.rows_lds = fits(blob_bytes_rows);
+    const bool forced = std::getenv("MTP_BLOB_PREFIX") != nullptr;   // (then exactly the planned prefix is copied)
+    L.rows_lds = forced ? (int) blob == blob_bytes_rows : fits(blob_bytes_rows);
     if (const char *e = std::getenv("MTP_ROWS_LDS")) L.rows_lds = L.rows_lds && std::atoi(e) != 0;   // tuning override
-    L.tgt_lds = L.rows_lds || fits(blob_bytes_tgt);
-    L.blob_bytes = L.rows_lds ? blob_bytes_rows : (fits(blob_bytes_norows) ? blob_bytes_norows : (L.tgt_lds ? blob_bytes_tgt : blob_bytes_core));
+    L.tgt_lds = forced ? (int) blob >= blob_bytes_tgt : (L.rows_lds || fits(blob_bytes_tgt));
+    if (forced) L.blob_bytes = L.rows_lds ? blob_bytes_rows : std::min((int) blob, blob_bytes_norows);
+    else L.blob_bytes = L.rows_lds ? blob_bytes_rows : (fits(blob_bytes_norows) ? blob_bytes_norows : (L.tgt_lds ? blob_bytes_tgt : blob_bytes_core));
     L.wpb = best_w;
     L.wave_doubles = (int) (wb / 8);
     L.lds_bytes = (size_t) L.blob_bytes + wb * best_w;
@@ -289,7 +291,15 @@ void mtp_context::plan()
   // HBM / L2 instead) is taken only when it buys wavefronts per CU (level 20: 8 instead of 7 with the core prefix).
   for (int which : {0, 2}) {   // [0] fused force kernel, [2] its grade instantiation
     int best_waves = 0;
-    for (int bytes : {blob_bytes_rows, blob_bytes_norows, blob_bytes_tgt, blob_bytes_core}) {
+    std::vector<int> prefixes = {blob_bytes_rows, blob_bytes_norows, blob_bytes_tgt, blob_bytes_core};
+    if (const char *e = std::getenv("MTP_BLOB_PREFIX")) {   // tuning / test override: plan against one prefix only
+      const std::string v(e);
+      if (v == "core") prefixes = {blob_bytes_core};
+      else if (v == "tgt") prefixes = {blob_bytes_tgt};
+      else if (v == "norows") prefixes = {blob_bytes_norows};
+      else if (v == "rows") prefixes = {blob_bytes_rows};
+    }
+    for (int bytes : prefixes) {
       LaunchPlan L;
       const int v = plan_one(which, (size_t) bytes, L);
       if (v > best_waves) {

@@ -99,6 +99,16 @@ def test_schedule_corner_cases_late_writer_and_shared_scalar(tmp_path, monkeypat
         _compare(dst, _system((3, 3, 3), species))
 
 
+@pytest.mark.parametrize("prefix", ["core", "tgt", "norows", "rows"])
+def test_every_table_blob_prefix(monkeypatch, prefix):
+    """The workgroup-shared tables are copied into LDS as one of four prefixes [core | scatter targets | basic
+    descriptors | rows + leaf constants]; what is left out is read from HBM / L2 (csrc/mtp_context.hip, plan()).  Each
+    prefix, forced, against the oracle -- levels 16 (row-per-lane passes) and 20 (gather passes)."""
+    monkeypatch.setenv("MTP_BLOB_PREFIX", prefix)
+    _compare(os.path.join(POT, "W_L16.mtp"), _system((3, 3, 3)))
+    _compare(os.path.join(POT, "WRe_L20.mtp"), _system((3, 3, 3), species=2))
+
+
 def test_many_in_cutoff_neighbours_multi_tile():
     """compressed lattice: 58 neighbours inside 5 A -> more than one 32-neighbour LDS tile"""
     s = _system((4, 4, 4), a=2.6, list_cutoff=6.0)
