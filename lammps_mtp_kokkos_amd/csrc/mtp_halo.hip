@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -48,6 +50,21 @@ __global__ void __launch_bounds__(256) halo_pack_kernel(const double *__restrict
   if (e >= n3) return;
   const int k = e / 3, c = e - 3 * k;
   out[e] = x[3 * (size_t) idx[k] + c] + shift[e];
+}
+
+// The same with the step's force array zeroed beside it (mtp_halo_force_step: one launch instead of two; f is 16-byte
+// aligned, nz doubles, nz - 2 * (nz / 2) in {0, 1})
+__global__ void __launch_bounds__(256) halo_pack_zero_kernel(const double *__restrict__ x, const int *__restrict__ idx,
+                                                            const double *__restrict__ shift, double *__restrict__ out,
+                                                            int n3, double *__restrict__ f, size_t nz)
+{
+  const size_t e = (size_t) blockIdx.x * 256 + threadIdx.x;
+  if (e < (size_t) n3) {
+    const int k = (int) e / 3, c = (int) e - 3 * k;
+    out[e] = x[3 * (size_t) idx[k] + c] + shift[e];
+  }
+  if (e < nz / 2) reinterpret_cast<double2 *>(f)[e] = make_double2(0.0, 0.0);
+  if (e == 0 && (nz & 1)) f[nz - 1] = 0.0;
 }
 
 // f[send_idx[k]] += frecv[k]: an owned atom can be a ghost on several peers (and several images), so the adds
@@ -304,11 +321,26 @@ int mtp_halo_force_step(mtp_halo *h, mtp_context *ctx, void *stream, int rows_a,
                         double *d_vatom, double *d_ev, double *d_grades, double *d_max_grade, double *d_coeff_ders)
 {
   if (!h || !ctx || !d_x || !d_f || rows_a < 0 || rows_b < 0 || rows_c < 0) return MTP_ERR_ARG;
-  if (mtp_zero_async(stream, d_f, 3ll * (h->nlocal + h->nghost)) != MTP_OK) {
-    h->last_error = "zeroing f failed";
+  if (reinterpret_cast<uintptr_t>(d_f) & 15u) return MTP_ERR_ARG;
+  int rc = MTP_OK;
+  try {   // forward_begin with the zeroing of f folded into the pack launch
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HIP_OK(hipSetDevice(h->device));
+    const int n3 = 3 * h->nsend;
+    const size_t nz = 3 * (size_t) (h->nlocal + h->nghost), work = std::max<size_t>((size_t) n3, (nz + 1) / 2);
+    if (work > 0) {
+      hipLaunchKernelGGL(halo_pack_zero_kernel, dim3((unsigned) ((work + 255) / 256)), dim3(256), 0, st, d_x, h->d_send_idx,
+                         h->d_send_shift, h->d_sendbuf, n3, d_f, nz);
+      HIP_OK(hipGetLastError());
+    }
+    HIP_OK(hipEventRecord(h->ev_fwd_ready, st));
+    HIP_OK(hipStreamWaitEvent(h->comm_stream, h->ev_fwd_ready, 0));
+    exchange(h, h->d_sendbuf, h->send_off, h->send_counts, d_x + 3 * (size_t) h->nlocal, h->recv_off, h->recv_counts);
+    HIP_OK(hipEventRecord(h->ev_fwd_done, h->comm_stream));
+  } catch (const HaloFail &f) {
+    h->last_error = f.what;
     return MTP_ERR_DEVICE;
   }
-  int rc = mtp_halo_forward_begin(h, stream, d_x);
   if (rc == MTP_OK && rows_a > 0)
     rc = mtp_compute_device_rows(ctx, stream, 0, rows_a, 0, d_x, d_type, eflag, vflag, grade_flag, d_f, d_eatom, d_vatom,
                                  d_ev, d_grades, d_max_grade, d_coeff_ders);
