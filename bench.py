@@ -177,6 +177,8 @@ def main():
         halo_kind = "native"
         halo = capi.Halo(plan, devidx, capi.halo_unique_id())
         halo_info = halo.comm_count()
+        if os.environ.get("MTP_BENCH_HALO_OVERLAP", "0") != "0":
+            halo.set_overlap(True)
     elif world > 1:
         if halo_kind == "native":
             # every rank must end up on the same path: the outcome of the (collective) creation is agreed on below
@@ -188,6 +190,8 @@ def main():
                 uid = bytes(store.get("mtp_halo_unique_id"))
                 halo = capi.Halo(plan, devidx, uid)
                 halo_info = halo.comm_count()
+                if os.environ.get("MTP_BENCH_HALO_OVERLAP", "0") != "0":
+                    halo.set_overlap(True)
                 assert halo_info["nranks"] == world and halo_info["rank"] == rank
             except Exception as exc:      # reported in the JSON line; the torch twin keeps the scaling run alive
                 ok, halo_note = 0, "library halo unavailable (%s: %s)" % (type(exc).__name__, exc)
@@ -411,7 +415,9 @@ def main():
                            "library halo: grouped RCCL send/recv per direction (communicator of %d ranks, RCCL %d)"
                            % (halo_info["nranks"], halo_info["rccl_version"]) if halo_info else "torch all-to-all halo (%s)%s" % (
                                backend, "; " + halo_note if halo_note else ""),
-                           ", rows interior|boundary|interior = %d|%d|%d overlap both exchanges" % (n_a, n_b, n_c) if use_rows else ""))
+                           (", rows interior|boundary|interior = %d|%d|%d overlap both exchanges" % (n_a, n_b, n_c)
+                            if (use_rows and (halo_kind != "native" or halo.overlap)) else
+                            ", one stream: pack, forward exchange, all rows in one launch, reverse exchange, unpack")))
                        if decomposed else ("single GPU, step replayed from a HIP graph" if run_step is not step else "single GPU"),
                        "atoms_rank0": plan.nlocal, "ghosts_rank0": plan.nghost, "list_entries_rank0": int(plan.first[-1]),
                        "in_cutoff_pairs_rank0": jc_total, "launch": info,

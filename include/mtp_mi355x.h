@@ -221,14 +221,19 @@ int mtp_halo_forward(mtp_halo *halo, void *stream, double *d_x);
 int mtp_halo_reverse_begin(mtp_halo *halo, void *stream, const double *d_f /*[nall][3]*/);
 int mtp_halo_reverse_end(mtp_halo *halo, void *stream, double *d_f);
 int mtp_halo_reverse(mtp_halo *halo, void *stream, double *d_f);
-/* One domain-decomposed force call with both exchanges overlapped.  The installed list must be ordered interior |
- * boundary | interior (rows_a + rows_b + rows_c = inum; interior = no ghost in the atom's list): zero d_f, forward
- * halo || rows [0, rows_a), boundary rows, reverse halo || the last rows_c rows, fold; tallies folded into d_ev by
- * the last force launch.  Everything is asynchronous on `stream` and the halo's stream. */
+/* One domain-decomposed force call (Comm::forward_comm, Pair::compute, Comm::reverse_comm of a LAMMPS step,
+ * pair_mtp.cpp:252-254, 315): zero d_f, ghost positions in, forces of the rows_a + rows_b + rows_c = inum rows, ghost
+ * forces back onto their owners, tallies folded into d_ev by the last force launch.  Default schedule: everything
+ * on `stream` -- pack, forward group, one launch over all rows, reverse group, unpack (measured faster on MI355X than
+ * the overlapped one at every domain size tried).  mtp_halo_set_overlap(halo, 1): both exchanges overlapped -- the
+ * installed list must then be ordered interior | boundary | interior (interior = no ghost in the atom's list): forward
+ * halo || rows [0, rows_a), boundary rows, reverse halo || the last rows_c rows, on `stream` and the halo's stream. */
 int mtp_halo_force_step(mtp_halo *halo, mtp_context *ctx, void *stream, int rows_a, int rows_b, int rows_c,
                         double *d_x, const int *d_type, int eflag, int vflag, int grade_flag, double *d_f,
                         double *d_eatom, double *d_vatom, double *d_ev, double *d_grades, double *d_max_grade,
                         double *d_coeff_ders);
+int mtp_halo_set_overlap(mtp_halo *halo, int enable);
+int mtp_halo_get_overlap(const mtp_halo *halo);
 /* in-place ncclAllReduce of `count` doubles: energy / virial and the configuration-mode candidate vector (SUM,
  * pair_mtp_extrapolation.cpp:369), the neighbourhood-mode maximum grade (MAX, :379) */
 int mtp_halo_allreduce(mtp_halo *halo, void *stream, double *d_buf, int count, int op);

@@ -27,7 +27,8 @@ EXPORTS = [
     "mtp_copy_neighbors_to_host", "mtp_compute_device_rows", "mtp_context_plan_info",
     "mtp_halo_get_unique_id", "mtp_halo_create", "mtp_halo_destroy", "mtp_halo_last_error", "mtp_halo_comm_count",
     "mtp_halo_forward_begin", "mtp_halo_forward_end", "mtp_halo_forward", "mtp_halo_reverse_begin",
-    "mtp_halo_reverse_end", "mtp_halo_reverse", "mtp_halo_allreduce", "mtp_halo_force_step",
+    "mtp_halo_reverse_end", "mtp_halo_reverse", "mtp_halo_allreduce", "mtp_halo_force_step", "mtp_halo_set_overlap",
+    "mtp_halo_get_overlap",
     "mtp_ghosts_create", "mtp_ghosts_destroy", "mtp_ghosts_last_error", "mtp_ghosts_build", "mtp_ghosts_forward",
     "mtp_ghosts_reverse", "mtp_ghosts_types", "mtp_nve_initial", "mtp_nve_final", "mtp_nve_monitor",
     "mtp_context_set_deterministic", "mtp_zero_async",
@@ -368,7 +369,9 @@ class Halo:
 
     def force_step(self, ctx, rows, x_t, type_t, f_t, eflag=0, vflag=0, grade=False, eatom_t=None, vatom_t=None, ev_t=None,
                    grades_t=None, maxg_t=None, coeff_t=None, stream=None):
-        """zero f, forward halo || interior rows, boundary rows, reverse halo || interior rows, fold (one C call)"""
+        """One decomposed force call (one C call).  Default: zero f + pack, forward exchange, all rows in one launch,
+        reverse exchange, unpack, on one stream; after set_overlap(True): forward halo || interior rows, boundary rows,
+        reverse halo || interior rows (rows = (nA, nB, nC) of domain.overlap_order)."""
         na, nb, nc = rows
         rc = lib().mtp_halo_force_step(self.h, ctx.h, self._st(stream), int(na), int(nb), int(nc), _ptr(x_t), _ptr(type_t),
                                        int(eflag), int(vflag), int(bool(grade)), _ptr(f_t), _ptr(eatom_t), _ptr(vatom_t),
@@ -376,6 +379,13 @@ class Halo:
         if rc:
             msg = lib().mtp_halo_last_error(self.h).decode() or lib().mtp_last_error(ctx.h).decode()
             raise MtpError(rc, msg)
+
+    def set_overlap(self, enable):
+        self._check(lib().mtp_halo_set_overlap(self.h, int(bool(enable))))
+
+    @property
+    def overlap(self):
+        return bool(lib().mtp_halo_get_overlap(self.h))
 
     def allreduce(self, buf_t, op=REDUCE_SUM, stream=None):
         self._check(lib().mtp_halo_allreduce(self.h, self._st(stream), _ptr(buf_t), int(buf_t.numel()), int(op)))

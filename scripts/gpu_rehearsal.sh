@@ -1,5 +1,6 @@
 #!/bin/bash
-# The decomposed step on ONE GPU (self halo) next to the plain step at 8192 / 16000 / 31250 / 65536 atoms:
+# The decomposed step on ONE GPU (self halo; default one-stream schedule and the overlapped one) next to the plain step
+# at 8192 / 16000 / 31250 / 65536 atoms:
 #   bash scripts/gpu_rehearsal.sh r02   -> gpurun_out/<tag>_profiles/<tag>_self_halo_rehearsal.json (best of 2 runs each)
 TAG=${1:-r02}
 OUT=gpurun_out/${TAG}_profiles
@@ -8,8 +9,8 @@ python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1 || { ta
 echo '[' > $OUT/${TAG}_self_halo_rehearsal.json
 first=1
 for c in 16 20 25 32; do
-  for mode in plain self; do
-    envs="A=1"; [ $mode = self ] && envs="MTP_BENCH_SELF_HALO=1"
+  for mode in plain self self_overlap; do
+    envs="A=1"; [ $mode = self ] && envs="MTP_BENCH_SELF_HALO=1"; [ $mode = self_overlap ] && envs="MTP_BENCH_SELF_HALO=1 MTP_BENCH_HALO_OVERLAP=1"
     for rep in 1 2; do
       env $envs timeout -k 10 200 python bench.py --cells $c --steps 300 --warmup 20 --no-cpu-baseline --no-whole-step > $OUT/sh$rep.json 2> $OUT/sh.err
     done

@@ -75,12 +75,17 @@ def test_allreduce_sum_and_max_single_rank(rank0):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("potential,grade", [("W_L16.mtp", False), ("W_L16_nbh.almtp", True)])
-def test_overlapped_step_matches_single_shot_call_and_oracle(rank0, potential, grade):
-    """forward halo || interior rows, boundary rows, reverse halo || interior rows, through the RCCL self-exchange."""
+def test_decomposed_step_matches_single_shot_call_and_oracle(rank0, potential, grade, overlap):
+    """mtp_halo_force_step through the RCCL self-exchange, both schedules: one stream (pack, forward exchange, all rows,
+    reverse exchange, unpack -- the default) and overlapped (forward halo || interior rows, boundary rows, reverse halo
+    || interior rows)."""
     import torch
     from oracle.pyoracle import Oracle
     plan, halo, dev, stream = rank0
+    halo.set_overlap(overlap)
+    assert halo.overlap == overlap
     path = os.path.join(POT, potential)
     pot = capi.Potential(path, selection=grade)
     ctx = capi.Context(pot, 0)
