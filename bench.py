@@ -229,6 +229,27 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.synchronize(stream)
+    # Which schedule of the decomposed step (one stream | exchanges overlapped with interior rows) is faster depends on
+    # how long an exchange takes on the fabric at hand: unless MTP_BENCH_HALO_OVERLAP pins it, both are timed in the
+    # warm-up (max over ranks, so every rank decides alike) and the faster one runs the timed steps.
+    schedule_probe = None
+    if decomposed and halo_kind == "native" and use_rows and "MTP_BENCH_HALO_OVERLAP" not in os.environ:
+        probe = {}
+        for mode in (False, True):
+            halo.set_overlap(mode)
+            for _ in range(5):
+                step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                step()
+            fence()
+            tp = torch.tensor([(time.perf_counter() - t0) / 20], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            probe[mode] = float(tp.item())
+        halo.set_overlap(probe[True] < probe[False])
+        schedule_probe = {"one_stream_ms": probe[False] * 1e3, "overlapped_ms": probe[True] * 1e3}
     run_step = step
     if args.graph and world == 1 and not decomposed:
         # the library's device path only launches kernels on the caller's stream, so a step can be captured and replayed
@@ -420,7 +441,7 @@ def main():
                             ", one stream: pack, forward exchange, all rows in one launch, reverse exchange, unpack")))
                        if decomposed else ("single GPU, step replayed from a HIP graph" if run_step is not step else "single GPU"),
                        "atoms_rank0": plan.nlocal, "ghosts_rank0": plan.nghost, "list_entries_rank0": int(plan.first[-1]),
-                       "in_cutoff_pairs_rank0": jc_total, "launch": info,
+                       "in_cutoff_pairs_rank0": jc_total, "launch": info, "halo_schedule_probe": schedule_probe,
                        "device_list_build_ms": list_build_ms},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
