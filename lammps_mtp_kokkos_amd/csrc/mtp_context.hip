@@ -1091,6 +1091,22 @@ int mtp_debug_read_stamps(mtp_context *c, unsigned long long *out16)
   return MTP_OK;
 }
 
+}   // extern "C"
+
+int mtp_internal_finish_unpack(mtp_context *c, void *stream, int eflag, int vflag, double *d_ev, double *d_f, const int *d_idx,
+                               const double *d_frecv, int n3)
+{
+  if (!c || !d_f || n3 < 0) return MTP_ERR_ARG;
+  const int fold = ((eflag & MTP_ENERGY_GLOBAL) || vflag) ? 1 : 0;
+  if (fold && !d_ev) return MTP_ERR_ARG;
+  if (!fold && n3 == 0) return MTP_OK;
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+  return mtp_launch_ev_finish_unpack(c->d_ev_slots.ptr, d_ev, fold, d_f, d_idx, d_frecv, n3, st) == hipSuccess ? MTP_OK
+                                                                                                                : MTP_ERR_DEVICE;
+}
+
+extern "C" {
+
 int mtp_zero_async(void *stream, double *d_p, long long n)
 {
   if (n < 0 || (n > 0 && !d_p) || (reinterpret_cast<uintptr_t>(d_p) & 15u)) return MTP_ERR_ARG;

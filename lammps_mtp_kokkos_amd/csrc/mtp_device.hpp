@@ -113,6 +113,13 @@ int mtp_pick_fwd_shape(int nblk, int *KL, int *NB);
 hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);
 bool mtp_wave_kernel_has_wps3(int nfb, int P);
 hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st);
+hipError_t mtp_launch_ev_finish_unpack(double *ev_slots, double *ev, int fold, double *f, const int *idx, const double *frecv,
+                                       int n3, hipStream_t st);
+// internal to the library (mtp_halo.hip): the tally fold of a step whose last force launch ran with finish_tallies = 0,
+// together with the fold of the received ghost forces, in one launch
+struct mtp_context;
+int mtp_internal_finish_unpack(mtp_context *c, void *stream, int eflag, int vflag, double *d_ev, double *d_f, const int *d_idx,
+                               const double *d_frecv, int n3);
 hipError_t mtp_launch_fixed_to_force(long long *fq, double *f, int nall, hipStream_t st);
 hipError_t mtp_launch_zero(double *p, size_t n, hipStream_t st);
 // radial block of cvec from dbasic (grade calls, after the force kernel)

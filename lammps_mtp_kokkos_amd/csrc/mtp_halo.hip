@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/mtp_mi355x.h"
+#include "mtp_device.hpp"
 
 namespace {
 
@@ -341,13 +342,12 @@ int mtp_halo_force_step(mtp_halo *h, mtp_context *ctx, void *stream, int rows_a,
         HIP_OK(hipGetLastError());
       }
       exchange(h, h->d_sendbuf, h->send_off, h->send_counts, d_x + 3 * (size_t) h->nlocal, h->recv_off, h->recv_counts, st);
-      rc = mtp_compute_device_rows(ctx, stream, 0, rows_a + rows_b + rows_c, 1, d_x, d_type, eflag, vflag, grade_flag, d_f,
+      // (finish_tallies = 0: the tally fold rides in the unpack launch behind the reverse exchange)
+      rc = mtp_compute_device_rows(ctx, stream, 0, rows_a + rows_b + rows_c, 0, d_x, d_type, eflag, vflag, grade_flag, d_f,
                                    d_eatom, d_vatom, d_ev, d_grades, d_max_grade, d_coeff_ders);
       exchange(h, d_f + 3 * (size_t) h->nlocal, h->recv_off, h->recv_counts, h->d_frecv, h->send_off, h->send_counts, st);
-      if (n3 > 0) {
-        hipLaunchKernelGGL(halo_unpack_add_kernel, dim3((n3 + 255) / 256), dim3(256), 0, st, d_f, h->d_send_idx, h->d_frecv, n3);
-        HIP_OK(hipGetLastError());
-      }
+      const int rc2 = mtp_internal_finish_unpack(ctx, stream, eflag, vflag, d_ev, d_f, h->d_send_idx, h->d_frecv, n3);
+      if (rc == MTP_OK) rc = rc2;
     } catch (const HaloFail &f) {
       h->last_error = f.what;
       return MTP_ERR_DEVICE;

@@ -1243,6 +1243,40 @@ __global__ void __launch_bounds__(512) mtp_ev_finish(double *ev_slots, double *e
   }
 }
 
+// The tally fold and the fold of the received ghost forces of a decomposed step in one launch (mtp_halo_force_step):
+// workgroups [0, 7) are mtp_ev_finish (when `fold`), the others add frecv[e] onto f[3 idx[e / 3] + e % 3] (fp64
+// atomics: an owned atom can be a ghost on several peers).
+__global__ void __launch_bounds__(512) mtp_ev_finish_unpack(double *ev_slots, double *ev, int fold, double *__restrict__ f,
+                                                           const int *__restrict__ idx, const double *__restrict__ frecv,
+                                                           int n3)
+{
+  if (blockIdx.x >= 7) {
+    const int e = (blockIdx.x - 7) * 512 + threadIdx.x;
+    if (e < n3) {
+      const int k = e / 3, c = e - 3 * k;
+      unsafeAtomicAdd(&f[3 * (size_t) idx[k] + c], frecv[e]);
+    }
+    return;
+  }
+  if (!fold) return;   // (whole workgroup)
+  __shared__ double part[8];
+  const int q = blockIdx.x;   // 0..6
+  double s = 0.0;
+  for (int k = threadIdx.x; k < MTP_EV_SLOTS; k += 512) {
+    s += ev_slots[8 * (size_t) k + q];
+    ev_slots[8 * (size_t) k + q] = 0.0;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) t += part[w];
+    ev[q] += t;
+  }
+}
+
 // f[0, n) = 0 in one launch (hipMemsetAsync splits into two fill kernels for sizes that are not multiples of its tile)
 __global__ void __launch_bounds__(256) mtp_zero_kernel(double2 *__restrict__ p, size_t n2, double *__restrict__ tail, int ntail)
 {
@@ -1548,6 +1582,13 @@ hipError_t mtp_launch_colsum_kernel(const double *cvec, int cpad, int C, int inu
 hipError_t mtp_launch_fixed_to_force(long long *fq, double *f, int nall, hipStream_t st)
 {
   hipLaunchKernelGGL(mtp_fixed_to_force, dim3((3 * nall + 255) / 256), dim3(256), 0, st, fq, f, 3 * nall);
+  return hipGetLastError();
+}
+
+hipError_t mtp_launch_ev_finish_unpack(double *ev_slots, double *ev, int fold, double *f, const int *idx, const double *frecv,
+                                       int n3, hipStream_t st)
+{
+  hipLaunchKernelGGL(mtp_ev_finish_unpack, dim3(7 + (n3 + 511) / 512), dim3(512), 0, st, ev_slots, ev, fold, f, idx, frecv, n3);
   return hipGetLastError();
 }
 
