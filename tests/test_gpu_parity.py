@@ -75,7 +75,7 @@ def test_level20_two_species():
     _compare(os.path.join(POT, "WRe_L20.mtp"), _system((3, 3, 3), species=2))
 
 
-@pytest.mark.parametrize("level,species", [(6, 1), (10, 3), (12, 2), (14, 1), (18, 1), (22, 1)])
+@pytest.mark.parametrize("level,species", [(4, 1), (6, 1), (10, 3), (12, 2), (14, 1), (18, 1), (22, 1)])   # (level 4: its one product is a leaf row)
 def test_other_levels_and_species(tmp_path, level, species):
     # levels 2 and 4 are not loadable by the reference either: its line buffers are sized from the (tiny) table
     # counts and truncate e.g. "alpha_index_times = {}" (pair_mtp.cpp:522-531); the parser here mirrors that
