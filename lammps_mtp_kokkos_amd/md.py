@@ -51,7 +51,6 @@ class DeviceNVE:
         self.cap = 0
         self._alloc(int(self.n * 1.6) + 1024, pos, types_np)
         self.v = torch.zeros((self.n, 3), dtype=torch.float64, device=self.dev)
-        self.ev = torch.zeros(8, dtype=torch.float64, device=self.dev)
         self.mon = torch.zeros(2, dtype=torch.float64, device=self.dev)
         self.x_ref = torch.empty((self.n, 3), dtype=torch.float64, device=self.dev)
         self.steps_since_build = 0
@@ -79,7 +78,10 @@ class DeviceNVE:
             xall[: self.n] = self.xall[: self.n]
             tall[: self.n] = self.types_all[: self.n]
         self.xall, self.types_all = xall, tall
-        self.fall = torch.zeros((cap, 3), dtype=torch.float64, device=self.dev)
+        # forces and the energy / virial totals share one allocation, so that one launch zeroes both every step
+        self.fbuf = torch.zeros(3 * cap + 8, dtype=torch.float64, device=self.dev)
+        self.fall = self.fbuf[: 3 * cap].view(cap, 3)
+        self.ev = self.fbuf[3 * cap:]
         self.cap = cap
 
     # ---- ghosts + list (re-neighbouring), all on the device ----------------------------------------------------
@@ -102,8 +104,7 @@ class DeviceNVE:
 
     def _forces(self):
         self.ghosts.forward(self.xall, stream=self.st)
-        capi.zero_async(self.fall[: self.nall], stream=self.st)
-        self.ev.zero_()
+        capi.zero_async(self.fbuf, stream=self.st)      # f (all rows of the allocation) and ev in one launch
         self.ctx.compute_device(self.xall, self.types_all, self.fall, eflag=1, vflag=self.vflag, ev_t=self.ev,
                                 stream=self.st)
         self.ghosts.reverse(self.fall, stream=self.st)
