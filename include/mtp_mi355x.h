@@ -257,6 +257,9 @@ int mtp_ghosts_build(mtp_ghosts *g, void *stream, double *d_x /*[capacity][3]*/,
                      const double box[3], double rghost, int *nall_out);
 int mtp_ghosts_forward(mtp_ghosts *g, void *stream, double *d_x);   /* ghost rows <- owner + shift            */
 int mtp_ghosts_reverse(mtp_ghosts *g, void *stream, double *d_f);   /* owner rows += ghost rows (fp64 atomics) */
+/* The same together with the energy / virial fold of a force call made through mtp_compute_device_rows(...,
+ * finish_tallies = 0, ...): one launch instead of two (d_ev as in mtp_compute_device; eflag / vflag of that call). */
+int mtp_ghosts_reverse_finish(mtp_ghosts *g, mtp_context *ctx, void *stream, int eflag, int vflag, double *d_f, double *d_ev);
 int mtp_ghosts_types(mtp_ghosts *g, void *stream, int *d_type);     /* ghost types <- owner types              */
 /* fix nve (metal units: dtf = 0.5 dt ftm2v): v += dtf f / m; x += dt v   and   v += dtf f / m; masses per type */
 int mtp_nve_initial(void *stream, int nlocal, double *d_x, double *d_v, const double *d_f, const int *d_type,

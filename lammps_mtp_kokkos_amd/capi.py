@@ -30,7 +30,7 @@ EXPORTS = [
     "mtp_halo_reverse_end", "mtp_halo_reverse", "mtp_halo_allreduce", "mtp_halo_force_step", "mtp_halo_set_overlap",
     "mtp_halo_get_overlap",
     "mtp_ghosts_create", "mtp_ghosts_destroy", "mtp_ghosts_last_error", "mtp_ghosts_build", "mtp_ghosts_forward",
-    "mtp_ghosts_reverse", "mtp_ghosts_types", "mtp_nve_initial", "mtp_nve_final", "mtp_nve_monitor",
+    "mtp_ghosts_reverse", "mtp_ghosts_reverse_finish", "mtp_ghosts_types", "mtp_nve_initial", "mtp_nve_final", "mtp_nve_monitor",
     "mtp_context_set_deterministic", "mtp_zero_async",
 ]
 HALO_ID_BYTES = 128
@@ -426,6 +426,11 @@ class Ghosts:
 
     def reverse(self, f_t, stream=None):
         self._check(lib().mtp_ghosts_reverse(self.h, C.c_void_p(stream) if stream else None, _ptr(f_t)))
+
+    def reverse_finish(self, ctx, f_t, ev_t, eflag=0, vflag=0, stream=None):
+        """ghost forces onto their owners + the tally fold of a force call made with finish_tallies=False, one launch"""
+        self._check(lib().mtp_ghosts_reverse_finish(self.h, ctx.h, C.c_void_p(stream) if stream else None, int(eflag), int(vflag),
+                                                    _ptr(f_t), _ptr(ev_t)))
 
     def types(self, type_t, stream=None):
         self._check(lib().mtp_ghosts_types(self.h, C.c_void_p(stream) if stream else None, _ptr(type_t)))

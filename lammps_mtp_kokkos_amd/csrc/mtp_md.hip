@@ -15,6 +15,7 @@
 #include <string>
 
 #include "../../include/mtp_mi355x.h"
+#include "mtp_device.hpp"
 
 namespace {
 
@@ -284,6 +285,13 @@ int mtp_ghosts_reverse(mtp_ghosts *g, void *stream, double *d_f)
                        reinterpret_cast<hipStream_t>(stream), d_f, g->nlocal, g->d_owner, 3 * g->nghost);
   MD_HIP(hipGetLastError());
   return MTP_OK;
+}
+
+int mtp_ghosts_reverse_finish(mtp_ghosts *g, mtp_context *ctx, void *stream, int eflag, int vflag, double *d_f, double *d_ev)
+{
+  if (!g || !ctx || !d_f) return MTP_ERR_ARG;
+  // the tally fold of a force call made with finish_tallies = 0 rides in the launch that folds the ghost forces
+  return mtp_internal_finish_unpack(ctx, stream, eflag, vflag, d_ev, d_f, g->d_owner, d_f + 3 * (size_t) g->nlocal, 3 * g->nghost);
 }
 
 int mtp_ghosts_types(mtp_ghosts *g, void *stream, int *d_type)

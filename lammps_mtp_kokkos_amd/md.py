@@ -105,9 +105,10 @@ class DeviceNVE:
     def _forces(self):
         self.ghosts.forward(self.xall, stream=self.st)
         capi.zero_async(self.fbuf, stream=self.st)      # f (all rows of the allocation) and ev in one launch
-        self.ctx.compute_device(self.xall, self.types_all, self.fall, eflag=1, vflag=self.vflag, ev_t=self.ev,
-                                stream=self.st)
-        self.ghosts.reverse(self.fall, stream=self.st)
+        # (finish_tallies=False: the energy / virial fold rides in the launch that folds the ghost forces)
+        self.ctx.compute_device_rows(0, self.n, False, self.xall, self.types_all, self.fall, eflag=1, vflag=self.vflag,
+                                     ev_t=self.ev, stream=self.st)
+        self.ghosts.reverse_finish(self.ctx, self.fall, self.ev, eflag=1, vflag=self.vflag, stream=self.st)
 
     # ---- one velocity-Verlet step ------------------------------------------------------------------------------
     def step(self, dt):
