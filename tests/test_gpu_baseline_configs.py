@@ -143,6 +143,40 @@ def test_config2_64k_force_parity_on_balls(w64k):
     assert np.abs(s.fold_forces(got["f"]).sum(0)).max() < 1e-7
 
 
+def _threads():
+    try:
+        return max(1, min(len(os.sched_getaffinity(0)), 32))
+    except AttributeError:
+        return max(1, min(os.cpu_count() or 1, 32))
+
+
+def _full_parity_threaded(path, s):
+    """EVERY force, site energy, per-atom virial and the totals of a 65,536-atom call against the threaded oracle
+    (oracle/mtp_oracle_mt.c, pinned to the serial restatement in tests/test_oracle.py)."""
+    pot = capi.Potential(path)
+    ctx = capi.Context(pot, 0)
+    ctx.set_neighbors(s.ilist, s.first, s.neigh, s.nall)
+    got = ctx.compute(s.x, s.types, eflag=3, vflag=4)
+    want = _oracle(path).compute_mt(_threads(), s.x, s.types, s.ilist, s.first, s.neigh, eflag=3, vflag=4)
+    _close(got["f"], want["f"], "all forces (ghost rows included)")
+    _close(got["eatom"], want["eatom"], "all site energies", atol=1e-10)
+    _close(got["vatom"], want["vatom"], "all per-atom virials")
+    n = s.nlocal
+    assert abs(got["energy"] - want["energy"]) / n <= 1e-10 * max(1.0, abs(want["energy"]) / n)
+    _close(got["virial"], want["virial"], "virial", atol=1e-7, rtol=1e-10)
+
+
+def test_config2_64k_every_force_against_the_threaded_oracle(w64k):
+    _full_parity_threaded(os.path.join(POT, "W_L16.mtp"), w64k)
+
+
+def test_config4_shard_64k_level20_every_force_against_the_threaded_oracle():
+    """the per-GPU shard of the 512k-atom W-Re case: 65,536 atoms, level 20, two species"""
+    s = _wre((32, 32, 32))
+    assert s.nlocal == 65536
+    _full_parity_threaded(os.path.join(POT, "WRe_L20.mtp"), s)
+
+
 # ---- config 5: 65,536-atom W, neighbourhood grades every step -----------------------------------------------------
 
 def test_config5_64k_grades_and_forces(w64k):

@@ -257,3 +257,20 @@ def test_configuration_mode_grade(tmp_path):
     assert c[2 * 8] == s.nlocal                    # species slot counts atoms
     want = np.abs(pot.inverse_active_set @ c).max() / s.nlocal
     assert abs(want - r["max_grade"]) < 1e-12 * want
+
+
+@pytest.mark.parametrize("level,species,threads", [(16, 1, 4), (12, 2, 3)])
+def test_threaded_oracle_matches_serial_oracle(tmp_path, level, species, threads):
+    """oracle/mtp_oracle_mt.c (threads over atoms, atomic adds into the one force array: the all-cores CPU baseline and
+    the checker of the full 65,536-atom GPU parity tests) against the serial restatement: same per-atom arithmetic, so
+    only the order of the force / virial sums differs."""
+    _, path = _make(tmp_path, level, species)
+    s = _system((4, 4, 4), species)
+    o = Oracle(path)
+    a = o.compute(s.x, s.types, s.ilist, s.first, s.neigh, eflag=3, vflag=4)
+    b = o.compute_mt(threads, s.x, s.types, s.ilist, s.first, s.neigh, eflag=3, vflag=4)
+    assert np.abs(a["f"] - b["f"]).max() <= 1e-12 * max(1.0, np.abs(a["f"]).max())
+    assert np.array_equal(a["eatom"], b["eatom"])          # one thread per atom: bit-identical
+    assert abs(a["energy"] - b["energy"]) <= 1e-11 * max(1.0, abs(a["energy"]))
+    assert np.abs(a["virial"] - b["virial"]).max() <= 1e-10 * max(1.0, np.abs(a["virial"]).max())
+    assert np.abs(a["vatom"] - b["vatom"]).max() <= 1e-12 * max(1.0, np.abs(a["vatom"]).max())
