@@ -200,6 +200,23 @@ def test_config5_64k_grades_and_forces(w64k):
                        what="forces (grade call)")
 
 
+def test_config5_64k_every_grade_against_the_serial_oracle(w64k):
+    """all 65,536 neighbourhood grades, forces and site energies of one grade call (the serial oracle walks them in a
+    few seconds)"""
+    s = w64k
+    path = os.path.join(POT, "W_L16_nbh.almtp")
+    pot = capi.Potential(path, selection=True)
+    ctx = capi.Context(pot, 0)
+    ctx.set_neighbors(s.ilist, s.first, s.neigh, s.nall)
+    got = ctx.compute(s.x, s.types, eflag=3, vflag=0, grade=True)
+    want = _oracle(path, selection=True).compute(s.x, s.types, s.ilist, s.first, s.neigh, eflag=3, vflag=0,
+                                                 extrapolation=True, natoms=s.nlocal)
+    _close(got["grades"], want["grades"], "all grades", atol=1e-9, rtol=1e-9)
+    _close(got["f"], want["f"], "all forces (grade call)")
+    _close(got["eatom"], want["eatom"], "all site energies (grade call)", atol=1e-10)
+    assert abs(got["max_grade"] - want["grades"].max()) <= 1e-9 * max(1.0, want["grades"].max())
+
+
 # ---- config 4: W-Re level 20 (C = 622: the grade GEMM with operands from L2, mtp_grade_kernel<0>) ---------------
 
 def _wre(ncell, seed=4242, frac=0.10):
