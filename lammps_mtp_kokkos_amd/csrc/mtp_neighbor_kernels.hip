@@ -63,18 +63,12 @@ __global__ void nb_gather(const double *__restrict__ x, const int *__restrict__ 
   xs[3 * (size_t) k + 2] = x[3 * (size_t) j + 2];
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int l)   // l wave-uniform
-{
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
-}
-
 // One wavefront per cell (round 2; before: one thread per atom walking ~580 candidates on its own, 0.40 ms for the two
 // passes at 65 536 atoms).  The 27 cells around cell c are 9 runs of memory in cell order (the three cells along z are
-// adjacent); the lanes load 64 candidates of the concatenated runs at a time, and every owned atom of the cell is tested
-// against the 64 at once: its position comes from the lane that holds it (v_readlane), the hits are a ballot, their
-// places in the row a prefix popcount -- rows come out in the same order as the serial walk (runs ascending, atom ids
-// ascending inside a cell).  FILL = false counts (numneigh, max row length), FILL = true writes neigh[].
+// adjacent); the lanes hold the candidates of the concatenated runs in registers (12 chunks of 64 at a time: the usual
+// neighbourhood in one batch), and every owned atom of the cell is tested against a chunk at once: its position comes
+// through the scalar path, the hits are a ballot, their places in the row a prefix popcount -- rows come out in the
+// same order as the serial walk (runs ascending, atom ids ascending inside a cell).  FILL = false counts (numneigh, max row length), FILL = true writes neigh[].
 // SPLIT wavefronts share a cell: each loads every candidate but tests only the atoms a = sub (mod SPLIT) of the cell --
 // no dependence between them (an atom's row belongs to one wavefront), 4x shorter serial chains for small systems.
 template <bool FILL, int SPLIT>
@@ -107,37 +101,54 @@ __global__ __launch_bounds__(256) void nb_walk_cell(CellGrid g, int inum, double
     run_pre[r + 1] = run_pre[r] + (end - beg);
   }
   const int total = run_pre[9];
-  for (int at = cs; at < ce; at += 64) {   // the cell's atoms, 64 at a time (lane l holds atom at + l)
+  constexpr int NB = 12;   // candidate chunks (of 64) held in registers at a time: 27 cells of ~22 atoms are 10
+  for (int at = cs; at < ce; at += 64) {   // the cell's atoms, 64 at a time (lane l keeps the count of atom at + l)
     const int t = at + lane, nat = min(64, ce - at);
     const bool have = t < ce;
     const int il = have ? cell_atoms[t] : 0x7fffffff;
     const bool owned = il < inum;
     const unsigned long long owned_mask = __ballot(owned);
     if (owned_mask == 0ull) continue;   // ghosts have no row
-    const size_t tt = (size_t) (have ? t : cs);
-    const double xa = xs[3 * tt], ya = xs[3 * tt + 1], za = xs[3 * tt + 2];
     int cnt = 0;
     const int row0 = FILL && owned ? first[il] : 0;
-    for (int q0 = 0; q0 < total; q0 += 64) {
-      const int q = q0 + lane;
-      const bool cand = q < total;
-      int k = run_beg[0] + q;   // candidate index in cell order
+    for (int q0 = 0; q0 < total; q0 += 64 * NB) {
+      // the candidates of this batch, one per lane and chunk (kc = -1: none)
+      double xc[NB], yc[NB], zc[NB];
+      int kc[NB], jc[NB];
 #pragma unroll
-      for (int r = 1; r < 9; r++)
-        if (q >= run_pre[r]) k = run_beg[r] + (q - run_pre[r]);
-      const size_t kk = (size_t) (cand ? k : cs);
-      const double xc = xs[3 * kk], yc = xs[3 * kk + 1], zc = xs[3 * kk + 2];
-      const int j = FILL ? cell_atoms[kk] : 0;
+      for (int b = 0; b < NB; b++) {
+        const int q = q0 + 64 * b + lane;
+        const bool cand = q < total;
+        int k = run_beg[0] + q;   // candidate index in cell order
+#pragma unroll
+        for (int r = 1; r < 9; r++)
+          if (q >= run_pre[r]) k = run_beg[r] + (q - run_pre[r]);
+        const size_t kk = (size_t) (cand ? k : cs);
+        xc[b] = xs[3 * kk];
+        yc[b] = xs[3 * kk + 1];
+        zc[b] = xs[3 * kk + 2];
+        kc[b] = cand ? k : -1;
+        jc[b] = FILL ? cell_atoms[kk] : 0;
+      }
+      const int nb = min(NB, (total - q0 + 63) / 64);   // uniform
       for (int a = sub; a < nat; a += SPLIT) {   // uniform
         if (!((owned_mask >> a) & 1ull)) continue;
-        const double dx = xc - readlane_f64(xa, a), dy = yc - readlane_f64(ya, a), dz = zc - readlane_f64(za, a);
-        const bool hit = cand && k != at + a && dx * dx + dy * dy + dz * dz <= cutsq;
-        const unsigned long long m = __ballot(hit);
-        if (FILL) {
-          const int base = __builtin_amdgcn_readlane(row0, a) + __builtin_amdgcn_readlane(cnt, a);
-          if (hit) neigh[base + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u))] = j;
-        }
-        if (lane == a) cnt += __popcll(m);
+        // the atom's position through the scalar path (uniform address); its hits of this batch in a scalar
+        const int ta = __builtin_amdgcn_readfirstlane(at + a);
+        const double xi = xs[3 * (size_t) ta], yi = xs[3 * (size_t) ta + 1], zi = xs[3 * (size_t) ta + 2];
+        const int base = FILL ? __builtin_amdgcn_readlane(row0, a) + __builtin_amdgcn_readlane(cnt, a) : 0;
+        int hits = 0;
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+          if (b < nb) {   // uniform
+            const double dx = xc[b] - xi, dy = yc[b] - yi, dz = zc[b] - zi;
+            const bool hit = kc[b] >= 0 && kc[b] != ta && dx * dx + dy * dy + dz * dz <= cutsq;
+            const unsigned long long m = __ballot(hit);
+            if (FILL && hit)
+              neigh[base + hits + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u))] = jc[b];
+            hits += __popcll(m);
+          }
+        if (lane == a) cnt += hits;
       }
     }
     if (!FILL && owned && lane % SPLIT == sub) {
