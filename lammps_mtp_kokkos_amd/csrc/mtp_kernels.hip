@@ -1432,6 +1432,104 @@ __global__ void __launch_bounds__(512) mtp_grade_kernel_lds(const double *__rest
     atomicMax(reinterpret_cast<unsigned long long *>(max_grade), (unsigned long long) __double_as_longlong(wmax));
 }
 
+// Output-stationary form of the same contraction (round 2): the wavefront keeps the NT = cpad / 16 accumulator tiles of
+// its 16 atoms (16 atoms x cpad rows of Ainv) and walks K in slabs of four k-steps; a slab of Ainv (4 k-steps of EVERY
+// 16-row tile, 2 KB per tile, contiguous in the tiled layout) is staged through the double-buffered LDS by the
+// workgroup and the four A operands of the next slab are fetched while the current slab's 4 NT MFMAs run.  The
+// A-stationary kernel above first pulls its whole 16 x cpad block of candidate vectors into registers -- every
+// wavefront of the one-round launch at the same time, 84 MB with the matrix pipe idle -- and its MFMAs form one
+// dependent chain per tile; here the loads are spread over the K loop and NT independent chains are in flight.
+#ifndef MTP_GRADE_TPB
+#define MTP_GRADE_TPB 512
+#define MTP_GRADE_WPE 2
+#endif
+template <int NT, int TPB, int WPE>   // TPB threads per workgroup (TPB / 64 wavefronts of 16 atoms), WPE wavefronts per SIMD
+__global__ void __launch_bounds__(TPB, WPE) mtp_grade_kernel_os(const double *__restrict__ cvec,
+                                                          const double *__restrict__ ainv_t, int inum,
+                                                          const int *__restrict__ ilist, double *grades,
+                                                          double *max_grade)
+{
+  extern __shared__ double stage[];   // [2][NT * 256]
+  constexpr int cpad = 16 * NT, KS = 4 * NT, NSLAB = NT, slab_doubles = NT * 256;
+  constexpr int PF = (slab_doubles + TPB - 1) / TPB;   // doubles per thread per slab
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int atom0 = (blockIdx.x * (TPB / 64) + wave) * 16;
+  const bool live = atom0 < inum;     // idle wavefronts still take part in the staging and the barriers
+  const int li = lane & 15, lk = lane >> 4;
+  const int arow = min(atom0 + li, inum - 1);   // clamped: rows past the end are computed and dropped
+  const double *ap = cvec + (size_t) arow * cpad + lk;
+  // slab c, element e = tile * 256 + (u * 64 + lane)  <-  ainv_t[(tile * KS + 4 c) * 64 + (u * 64 + lane)]
+  auto src = [&](int c, int e) { return ainv_t[((size_t) (e >> 8) * KS + 4 * c) * 64 + (e & 255)]; };
+  double pf[PF], a_cur[4], a_nxt[4];
+#pragma unroll
+  for (int u = 0; u < PF; u++) {
+    const int e = threadIdx.x + TPB * u;
+    if (e < slab_doubles) stage[e] = src(0, e);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; u++) a_cur[u] = ap[4 * u];
+  __syncthreads();
+  double4_t acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+  for (int c = 0; c < NSLAB; c++) {
+    const double *cur = stage + (size_t) (c & 1) * slab_doubles + lane;
+    double *nxt = stage + (size_t) ((c + 1) & 1) * slab_doubles;
+    if (c + 1 < NSLAB) {
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        const int e = threadIdx.x + TPB * u;
+        pf[u] = e < slab_doubles ? src(c + 1, e) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) a_nxt[u] = ap[4 * (4 * (c + 1) + u)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[u], cur[(t * 4 + u) * 64], acc[t], 0, 0, 0);
+    if (c + 1 < NSLAB) {
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        const int e = threadIdx.x + TPB * u;
+        if (e < slab_doubles) nxt[e] = pf[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) a_cur[u] = a_nxt[u];
+    }
+    __syncthreads();
+  }
+  double gmax[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) gmax[r] = fmax(gmax[r], fabs(acc[t][r]));
+  // max over the 16 lanes (Ainv rows) that share l>>4
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    gmax[r] = fmax(gmax[r], partner_f64<1>(gmax[r]));
+    gmax[r] = fmax(gmax[r], partner_f64<2>(gmax[r]));
+    gmax[r] = fmax(gmax[r], partner_f64<4>(gmax[r]));
+    gmax[r] = fmax(gmax[r], partner_f64<8>(gmax[r]));
+  }
+  double wmax = 0.0;
+  if (live && li == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int a = atom0 + lk + 4 * r;   // D row = (l>>4) + 4*reg
+      if (a < inum) {
+        grades[ilist[a]] = gmax[r];   // pair_mtp_extrapolation.cpp:335
+        wmax = fmax(wmax, gmax[r]);
+      }
+    }
+  }
+  wmax = fmax(wmax, partner_f64<16>(wmax, lane));
+  wmax = fmax(wmax, partner_f64<32>(wmax, lane));
+  if (live && lane == 0 && max_grade)
+    atomicMax(reinterpret_cast<unsigned long long *>(max_grade), (unsigned long long) __double_as_longlong(wmax));
+}
+
 // configuration mode: coeff_ders[c] += sum_i cvec[i][c]  (pair_mtp_extrapolation.cpp:97-98, 240-252, 327)
 __global__ void __launch_bounds__(256) mtp_colsum_kernel(const double *__restrict__ cvec, int cpad, int C, int inum,
                                                         double *coeff_ders)
@@ -1561,7 +1659,23 @@ hipError_t mtp_launch_grade_kernel(const double *cvec, const double *ainv_pad, c
                                    int C, int inum, const int *ilist, double *grades, double *max_grade, hipStream_t st)
 {
   (void) C;
-  if (cpad <= 160 && ainv_tiled) {
+  static const bool use_os = !(std::getenv("MTP_GRADE_OS") && std::atoi(std::getenv("MTP_GRADE_OS")) == 0);   // tuning
+  if (cpad <= 160 && ainv_tiled && use_os) {
+    const size_t lds = (size_t) 2 * cpad * 16 * sizeof(double);
+    constexpr int TPB = MTP_GRADE_TPB, WPE = MTP_GRADE_WPE;
+    const dim3 grid((inum + TPB / 4 - 1) / (TPB / 4)), block(TPB);
+#define MTP_GRADE_OS_CASE(NT)                                                                                         \
+  case NT:                                                                                                            \
+    hipLaunchKernelGGL((mtp_grade_kernel_os<NT, TPB, WPE>), grid, block, lds, st, cvec, ainv_tiled, inum, ilist, grades,  \
+                       max_grade);                                                                                    \
+    break;
+    switch (cpad / 16) {
+      MTP_GRADE_OS_CASE(1) MTP_GRADE_OS_CASE(2) MTP_GRADE_OS_CASE(3) MTP_GRADE_OS_CASE(4) MTP_GRADE_OS_CASE(5)
+      MTP_GRADE_OS_CASE(6) MTP_GRADE_OS_CASE(7) MTP_GRADE_OS_CASE(8) MTP_GRADE_OS_CASE(9) MTP_GRADE_OS_CASE(10)
+      default: return hipErrorInvalidValue;
+    }
+#undef MTP_GRADE_OS_CASE
+  } else if (cpad <= 160 && ainv_tiled) {
     const size_t lds = (size_t) 2 * cpad * 16 * sizeof(double);
     hipLaunchKernelGGL(mtp_grade_kernel_lds<40>, dim3((inum + 127) / 128), dim3(512), lds, st, cvec, ainv_tiled, cpad,
                        inum, ilist, grades, max_grade);
