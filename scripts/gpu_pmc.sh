@@ -38,7 +38,7 @@ for name in ["sq1","sq2","sq3","tcc1","tcc2","tcc3"]:
             if "mtp_wave_kernel" in kn:
                 acc[("", row["Counter_Name"])].append(float(row["Counter_Value"]))
             else:
-                for short in ("mtp_grade_kernel_lds", "mtp_grade_kernel", "mtp_cvec_kernel", "mtp_ev_finish"):
+                for short in ("mtp_grade_kernel_os", "mtp_grade_kernel_lds", "mtp_grade_kernel", "mtp_cvec_kernel", "mtp_ev_finish"):
                     if short in kn:
                         acc[(short, row["Counter_Name"])].append(float(row["Counter_Value"]))
                         break
