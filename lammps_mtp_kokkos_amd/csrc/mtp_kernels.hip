@@ -40,7 +40,9 @@
 namespace {
 
 #ifndef MTP_PU
-#define MTP_PU 4   // times rows in flight per lane in the product passes
+#define MTP_PU 2   // times rows in flight per lane in the row-per-lane product passes (4 until the leaf moments and the
+                   // per-tile totals changed the balance: re-measured 1 / 2 / 3 / 4 / 5 / 6 rows: 0.473 / 0.473 / 0.477 / 0.482 /
+                   // 0.486 / 0.496 ms at level 16)
 #endif
 
 // The parameter block is read through the kernarg segment pointer (address space 4: scalar loads from the constant
