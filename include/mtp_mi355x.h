@@ -7,11 +7,17 @@
  *
  * Threading: one context per rank/GPU; calls on one context must be serialised by the
  * caller (the reference is not re-entrant either: member scratch buffers,
- * LAMMPS/ML-MTP/pair_mtp.h:70-83).  Device work is ordered on the stream given to the
- * `_device` entry points.  A NULL stream means the context's own stream, which is created
- * NON-BLOCKING: it does not synchronise with the legacy default stream, so a caller whose
- * other GPU work runs on the default stream (PyTorch's default) must pass a real stream
- * handle that its own work is ordered on, or synchronise around the calls.
+ * LAMMPS/ML-MTP/pair_mtp.h:70-83).
+ *
+ * Streams.  Device work is ordered on the `stream` (a hipStream_t) given to an entry point.  ONE rule for NULL:
+ *   - entry points that take a context (mtp_compute_device[_rows], mtp_build_neighbors_device,
+ *     mtp_set_neighbors_device_2d, mtp_synchronize, mtp_halo_force_step, mtp_ghosts_reverse_finish): NULL means the
+ *     context's own stream, resolved once per call -- every launch and RCCL group of that call runs on it;
+ *   - entry points without a context (the other mtp_halo_*, mtp_ghosts_*, mtp_nve_* calls, mtp_zero_async): NULL is
+ *     rejected with MTP_ERR_ARG -- there is no stream to map it to, and the legacy null stream is never used.
+ * The context's stream is created NON-BLOCKING: it does not synchronise with the legacy default stream, so a caller
+ * whose other GPU work runs on the default stream (PyTorch's default) must pass a real stream handle that its own
+ * work is ordered on, or synchronise around the calls.
  */
 #ifndef MTP_MI355X_H
 #define MTP_MI355X_H
@@ -22,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MTP_MI355X_ABI_VERSION 2
+#define MTP_MI355X_ABI_VERSION 3
 
 /* status codes (the reference aborts through error->one/all, pair_mtp.cpp:92,354-358;
  * the adapter turns a non-zero status + mtp_last_error() into error->all) */
@@ -107,6 +113,18 @@ int mtp_set_neighbors_csr(mtp_context *ctx, int inum, const int *ilist, const in
 /* CSR arrays already resident in HBM (no copy; must stay valid until replaced). */
 int mtp_set_neighbors_device(mtp_context *ctx, int inum, const int *d_ilist, const int *d_first,
                              const int *d_neigh, int nall, int max_numneigh);
+/* The list as LAMMPS-KOKKOS holds it on the device: the `/kk` styles of the reference read k_list->d_ilist(ii),
+ * d_numneigh(i) and the padded 2-D view d_neighbors(i, jj) (KOKKOS/pair_mtp_kokkos.cpp:236-239, pair_mtp_kokkos.h:115;
+ * `FindMaxNumNeighs`, pair_mtp_kokkos.cpp:177-191, 254-256).  Element (i, jj) is d_neighbors[i * stride_i + jj *
+ * stride_jj] -- LayoutLeft (the GPU default): stride_i = 1, stride_jj = extent(0); LayoutRight: stride_i = extent(1),
+ * stride_jj = 1 -- rows are indexed by atom index i = d_ilist[ii], max_neighs = extent(1).  Two device kernels and a
+ * scan compact the view into the context's CSR arrays (special-bond bits are kept and masked with NEIGHMASK in the
+ * force kernel, pair_mtp.cpp:114); d_ilist is used in place and must stay valid until the next list is installed.
+ * Nothing passes through the host except one 12-byte read-back (entry count, longest row), which synchronises
+ * `stream` once per re-neighbouring. */
+int mtp_set_neighbors_device_2d(mtp_context *ctx, void *stream, int inum, const int *d_ilist, const int *d_numneigh,
+                                const int *d_neighbors, long long stride_i, long long stride_jj, int max_neighs,
+                                int nall);
 /* Builds that list on the GPU from positions resident in HBM (what LAMMPS' Neighbor class
  * does ahead of the pair style, REQ_FULL at pair_mtp.cpp:317-318): a full list for atoms [0, inum) over all
  * nall atoms (owned first, then explicit ghosts -- no periodic images are invented), entries j != i with
@@ -161,6 +179,9 @@ int mtp_synchronize(mtp_context *ctx, void *stream);
  * once per step after the cross-rank sum). */
 int mtp_cfg_grade(const mtp_potential *pot, const double *coeff_ders, double *grade);
 
+/* Compile-time switches of this build that differ from the shipped defaults, space separated ("" for a release
+ * build: tests assert that the library they load carries none -- diagnostic variants are never shipped). */
+const char *mtp_build_flags(void);
 /* introspection for benchmarks: LDS bytes per wavefront, wavefronts per workgroup, grid */
 int mtp_context_launch_info(const mtp_context *ctx, int32_t *lds_bytes_per_wave, int32_t *waves_per_block,
                             int32_t *grid_blocks, int32_t *neighbor_tile);
@@ -201,7 +222,17 @@ enum { MTP_REDUCE_SUM = 0, MTP_REDUCE_MAX = 1 };
 
 /* ncclGetUniqueId: called on one rank; the caller passes the bytes to every rank (MPI_Bcast, a TCP store, a file) */
 int mtp_halo_get_unique_id(void *id_out /*[MTP_HALO_ID_BYTES]*/);
-/* ncclCommInitRank + device copies of the index lists: collective over all nranks processes */
+/* Host only, no device: the per-peer segment tables mtp_halo_create derives from the layout contract above -- peer q's
+ * segment starts at atom send_off[q] of the packed send buffer and at ghost recv_off[q]; arrays of nranks + 1 entries
+ * (last = totals) -- with the same checks (counts add up, send_idx inside the owned atoms).  These are the offsets the
+ * grouped ncclSend / ncclRecv of a direction use (the counterpart of LAMMPS' Comm sendlist / firstrecv bookkeeping
+ * the reference relies on, pair_mtp.cpp:252-254, 315). */
+int mtp_halo_layout(int nranks, int nlocal, int nghost, const int *send_idx, const int *send_counts,
+                    const int *recv_counts, int *send_off /*[nranks+1]*/, int *recv_off /*[nranks+1]*/, char *err,
+                    int errlen);
+/* ncclCommInitRank + device copies of the index lists: collective over all nranks processes.  unique_id == NULL
+ * creates the halo WITHOUT a communicator (no collective call): it packs, unpacks and answers mtp_halo_get_layout,
+ * and its segments are moved by mtp_halo_local_exchange or by the caller; the RCCL entry points then fail. */
 int mtp_halo_create(int device_id, int nranks, int rank, const void *unique_id, int nlocal, int nghost,
                     const int *send_idx /*[sum send_counts]*/, const double *send_shift /*[sum send_counts][3]*/,
                     const int *send_counts /*[nranks]*/, const int *recv_counts /*[nranks]*/, mtp_halo **out,
@@ -234,6 +265,21 @@ int mtp_halo_force_step(mtp_halo *halo, mtp_context *ctx, void *stream, int rows
                         double *d_coeff_ders);
 int mtp_halo_set_overlap(mtp_halo *halo, int enable);
 int mtp_halo_get_overlap(const mtp_halo *halo);
+/* The kernels either side of an exchange on their own: sendbuf[k] = d_x[send_idx[k]] + send_shift[k] (what
+ * mtp_halo_forward_begin launches ahead of its group) and d_f[send_idx[k]] += frecv[k] (what mtp_halo_reverse_end
+ * launches behind its group). */
+int mtp_halo_pack_forward(mtp_halo *halo, void *stream, const double *d_x);
+int mtp_halo_unpack_reverse(mtp_halo *halo, void *stream, double *d_f);
+/* the tables of this halo as the exchange uses them (arrays of nranks + 1 / nranks entries; any may be NULL) */
+int mtp_halo_get_layout(const mtp_halo *halo, int *nsend, int *send_off, int *send_counts, int *recv_off,
+                        int *recv_counts);
+/* Single-process rehearsal of an n-rank exchange: halos[r] = rank r of ONE n-rank decomposition, all on one device
+ * (created with or without a communicator).  direction 0 = forward: after mtp_halo_pack_forward on every rank, copies
+ * every (source q, destination r) segment into the ghost rows of d_arrays[r] (= rank r's positions [nall_r][3]);
+ * direction 1 = reverse: copies the ghost rows of d_arrays[r] (= rank r's forces) into the owners' receive buffers,
+ * to be folded by mtp_halo_unpack_reverse.  Device-to-device copies on `stream`, addressed with the same per-peer
+ * offset tables the RCCL groups use; fails when the two sides of a segment disagree on its length. */
+int mtp_halo_local_exchange(mtp_halo *const *halos, int n, void *stream, int direction, double *const *d_arrays);
 /* in-place ncclAllReduce of `count` doubles: energy / virial and the configuration-mode candidate vector (SUM,
  * pair_mtp_extrapolation.cpp:369), the neighbourhood-mode maximum grade (MAX, :379) */
 int mtp_halo_allreduce(mtp_halo *halo, void *stream, double *d_buf, int count, int op);

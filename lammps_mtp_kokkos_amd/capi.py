@@ -28,7 +28,8 @@ EXPORTS = [
     "mtp_halo_get_unique_id", "mtp_halo_create", "mtp_halo_destroy", "mtp_halo_last_error", "mtp_halo_comm_count",
     "mtp_halo_forward_begin", "mtp_halo_forward_end", "mtp_halo_forward", "mtp_halo_reverse_begin",
     "mtp_halo_reverse_end", "mtp_halo_reverse", "mtp_halo_allreduce", "mtp_halo_force_step", "mtp_halo_set_overlap",
-    "mtp_halo_get_overlap",
+    "mtp_halo_get_overlap", "mtp_halo_layout", "mtp_halo_pack_forward", "mtp_halo_unpack_reverse", "mtp_halo_get_layout",
+    "mtp_halo_local_exchange", "mtp_set_neighbors_device_2d", "mtp_build_flags",
     "mtp_ghosts_create", "mtp_ghosts_destroy", "mtp_ghosts_last_error", "mtp_ghosts_build", "mtp_ghosts_forward",
     "mtp_ghosts_reverse", "mtp_ghosts_reverse_finish", "mtp_ghosts_types", "mtp_nve_initial", "mtp_nve_final", "mtp_nve_monitor",
     "mtp_context_set_deterministic", "mtp_zero_async",
@@ -69,6 +70,7 @@ def lib():
         for n in EXPORTS:
             getattr(L, n).restype = C.c_int
         L.mtp_last_error.restype = C.c_char_p
+        L.mtp_build_flags.restype = C.c_char_p
         L.mtp_halo_last_error.restype = C.c_char_p
         L.mtp_ghosts_last_error.restype = C.c_char_p
         L.mtp_ghosts_destroy.restype = None
@@ -89,6 +91,26 @@ def kernel_source_hash():
             h.update(n.encode())
             h.update(open(os.path.join(src, n), "rb").read())
     return h.hexdigest()
+
+
+def build_flags():
+    """compile-time switches of the loaded library that differ from the shipped defaults ("" for a release build)"""
+    return lib().mtp_build_flags().decode()
+
+
+def halo_layout(plan):
+    """(send_off, recv_off) as the C side derives them from a plan's counts (host only: mtp_halo_layout)."""
+    idx = np.ascontiguousarray(plan.send_idx, np.int32)
+    sc = np.ascontiguousarray(plan.send_counts, np.int32)
+    rc_ = np.ascontiguousarray(plan.recv_counts, np.int32)
+    so = np.zeros(plan.nranks + 1, np.int32)
+    ro = np.zeros(plan.nranks + 1, np.int32)
+    err = C.create_string_buffer(512)
+    rc = lib().mtp_halo_layout(int(plan.nranks), int(plan.nlocal), int(plan.nghost), _np(idx, C.c_int), _np(sc, C.c_int),
+                               _np(rc_, C.c_int), _np(so, C.c_int), _np(ro, C.c_int), err, 512)
+    if rc:
+        raise MtpError(rc, err.value.decode())
+    return so, ro
 
 
 def use_private_torch_stream(device):
@@ -204,6 +226,16 @@ class Context:
         self._check(lib().mtp_set_neighbors(self.h, len(ilist), _np(ilist, C.c_int), _np(numneigh, C.c_int), arr,
                                             int(nall)))
 
+    def set_neighbors_device_2d(self, ilist_t, numneigh_t, neighbors_t, stride_i, stride_jj, max_neighs, nall, stream=None):
+        """LAMMPS-KOKKOS form: d_ilist(ii), d_numneigh(i), padded 2-D view d_neighbors(i, jj) with the given strides."""
+        self._keep = [ilist_t, numneigh_t, neighbors_t]
+        self.nall = int(nall)
+        self._inum = int(ilist_t.numel())
+        self._check(lib().mtp_set_neighbors_device_2d(self.h, C.c_void_p(stream) if stream else None, int(ilist_t.numel()),
+                                                      _ptr(ilist_t), _ptr(numneigh_t), _ptr(neighbors_t),
+                                                      C.c_longlong(stride_i), C.c_longlong(stride_jj), int(max_neighs),
+                                                      int(nall)))
+
     def set_neighbors_device(self, ilist_t, first_t, neigh_t, nall, max_numneigh):
         self._keep = [ilist_t, first_t, neigh_t]
         self.nall = int(nall)
@@ -314,7 +346,8 @@ def halo_unique_id():
 
 class Halo:
     """The library's RCCL halo (include/mtp_mi355x.h, "multi-GPU halo") for one rank of a decomposition
-    (domain.HaloPlan).  Creation is collective over all ranks."""
+    (domain.HaloPlan).  Creation is collective over all ranks -- unless unique_id is None: the halo then has no
+    communicator (pack / unpack / layout only; segments move through Halo.local_exchange)."""
 
     def __init__(self, plan, device, unique_id):
         self.plan = plan
@@ -323,7 +356,7 @@ class Halo:
         shift = np.ascontiguousarray(plan.send_shift, np.float64).reshape(-1, 3)
         sc = np.ascontiguousarray(plan.send_counts, np.int32)
         rc_ = np.ascontiguousarray(plan.recv_counts, np.int32)
-        assert len(unique_id) == HALO_ID_BYTES and len(sc) == plan.nranks == len(rc_)
+        assert (unique_id is None or len(unique_id) == HALO_ID_BYTES) and len(sc) == plan.nranks == len(rc_)
         err = C.create_string_buffer(512)
         rc = lib().mtp_halo_create(int(device), int(plan.nranks), int(plan.rank), unique_id, int(plan.nlocal),
                                    int(plan.nghost), _np(idx, C.c_int), _np(shift, C.c_double), _np(sc, C.c_int),
@@ -379,6 +412,31 @@ class Halo:
         if rc:
             msg = lib().mtp_halo_last_error(self.h).decode() or lib().mtp_last_error(ctx.h).decode()
             raise MtpError(rc, msg)
+
+    def pack_forward(self, x_t, stream):
+        self._check(lib().mtp_halo_pack_forward(self.h, self._st(stream), _ptr(x_t)))
+
+    def unpack_reverse(self, f_t, stream):
+        self._check(lib().mtp_halo_unpack_reverse(self.h, self._st(stream), _ptr(f_t)))
+
+    def layout(self):
+        n = self.plan.nranks
+        ns = C.c_int()
+        so, sc, ro, rc_ = (np.zeros(n + 1, np.int32), np.zeros(n, np.int32), np.zeros(n + 1, np.int32), np.zeros(n, np.int32))
+        self._check(lib().mtp_halo_get_layout(self.h, C.byref(ns), _np(so, C.c_int), _np(sc, C.c_int), _np(ro, C.c_int),
+                                              _np(rc_, C.c_int)))
+        return dict(nsend=ns.value, send_off=so, send_counts=sc, recv_off=ro, recv_counts=rc_)
+
+    @staticmethod
+    def local_exchange(halos, direction, arrays, stream):
+        """All ranks' exchange of one direction (0 forward: arrays = positions, 1 reverse: arrays = forces) between the
+        halo objects of one decomposition living in this process (mtp_halo_local_exchange)."""
+        n = len(halos)
+        hs = (C.c_void_p * n)(*[h.h for h in halos])
+        ps = (C.c_void_p * n)(*[t.data_ptr() for t in arrays])
+        rc = lib().mtp_halo_local_exchange(hs, n, C.c_void_p(stream), int(direction), ps)
+        if rc:
+            raise MtpError(rc, lib().mtp_halo_last_error(halos[0].h).decode())
 
     def set_overlap(self, enable):
         self._check(lib().mtp_halo_set_overlap(self.h, int(bool(enable))))

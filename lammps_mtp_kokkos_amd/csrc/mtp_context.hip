@@ -794,6 +794,70 @@ int mtp_build_neighbors_device(mtp_context *c, void *stream, const double *d_x, 
   }
 }
 
+int mtp_set_neighbors_device_2d(mtp_context *c, void *stream, int inum, const int *d_ilist, const int *d_numneigh,
+                                const int *d_neighbors, long long stride_i, long long stride_jj, int max_neighs, int nall)
+{
+  if (!c || inum < 0 || nall < inum || max_neighs < 0 || (inum > 0 && (!d_ilist || !d_numneigh)) || stride_i < 0 || stride_jj < 0)
+    return MTP_ERR_ARG;
+  if (inum > 0 && max_neighs > 0 && (!d_neighbors || (stride_i != 1 && stride_jj != 1))) {
+    c->last_error = "mtp_set_neighbors_device_2d: one of the two strides must be 1 (LayoutLeft or LayoutRight view)";
+    return MTP_ERR_ARG;
+  }
+  if (hipSetDevice(c->device) != hipSuccess) {
+    c->last_error = "hipSetDevice failed";
+    return MTP_ERR_DEVICE;
+  }
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+  try {
+    const size_t cub_bytes = mtp_neighbor_scan_bytes(inum + 1, 1);
+    c->d_nb_tmp.reserve(std::max<size_t>(cub_bytes, 16));
+    c->d_nb_scratch.reserve((size_t) inum + 1);
+    c->d_nb_info.reserve(4);
+    c->d_first.reserve((size_t) inum + 1);
+    HIP_CHECK(mtp_launch_list_from_2d(inum, d_ilist, d_numneigh, d_neighbors, stride_i, stride_jj, max_neighs,
+                                      c->d_nb_scratch.ptr, c->d_nb_tmp.ptr, c->d_nb_tmp.cap, c->d_first.ptr, nullptr,
+                                      c->d_nb_info.ptr, st));
+    int info[3] = {0, 0, 0};
+    HIP_CHECK(hipMemcpyAsync(info, c->d_nb_info.ptr, sizeof(info), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));   // one read-back per re-neighbouring sizes the entry array and the LDS plan
+    if (info[2]) {
+      c->last_error = "mtp_set_neighbors_device_2d: a d_numneigh entry is negative or exceeds the view's second extent";
+      return MTP_ERR_ARG;
+    }
+    if (info[0] < 0) {
+      c->last_error = "neighbour list has more than 2^31-1 entries on this rank";
+      return MTP_ERR_LIMIT;
+    }
+    c->d_neigh.reserve((size_t) std::max(info[0], 1));
+    HIP_CHECK(mtp_launch_list_from_2d(inum, d_ilist, d_numneigh, d_neighbors, stride_i, stride_jj, max_neighs,
+                                      c->d_nb_scratch.ptr, c->d_nb_tmp.ptr, c->d_nb_tmp.cap, c->d_first.ptr, c->d_neigh.ptr,
+                                      c->d_nb_info.ptr, st));
+    c->ilist = d_ilist;   // the caller's (KOKKOS') d_ilist stays in use: it must remain valid until the next list
+    c->first = c->d_first.ptr;
+    c->neigh = c->d_neigh.ptr;
+    c->list_stream = st;
+    return finish_list(c, inum, nall, info[1]);
+  } catch (const HipFail &f) {
+    c->last_error = std::string(f.what) + ": " + hipGetErrorString(f.e);
+    return MTP_ERR_DEVICE;
+  }
+}
+
+const char *mtp_build_flags(void)
+{
+  // compile-time switches that differ from the shipped defaults; "" for a release build (tests assert exactly that)
+  static const std::string flags = [] {
+    std::string f;
+#ifdef MTP_STAMPS
+    f += "MTP_STAMPS ";
+#endif
+    f += mtp_kernel_build_flags();
+    if (!f.empty() && f.back() == ' ') f.pop_back();
+    return f;
+  }();
+  return flags.c_str();
+}
+
 int mtp_copy_neighbors_to_host(mtp_context *c, int *first, int *neigh)
 {
   if (!c || !first) return MTP_ERR_ARG;
@@ -1093,6 +1157,11 @@ int mtp_debug_read_stamps(mtp_context *c, unsigned long long *out16)
 
 }   // extern "C"
 
+void *mtp_internal_resolve_stream(mtp_context *c, void *stream)
+{
+  return stream ? stream : (c ? reinterpret_cast<void *>(c->stream) : nullptr);
+}
+
 int mtp_internal_finish_unpack(mtp_context *c, void *stream, int eflag, int vflag, double *d_ev, double *d_f, const int *d_idx,
                                const double *d_frecv, int n3)
 {
@@ -1110,6 +1179,7 @@ extern "C" {
 int mtp_zero_async(void *stream, double *d_p, long long n)
 {
   if (n < 0 || (n > 0 && !d_p) || (reinterpret_cast<uintptr_t>(d_p) & 15u)) return MTP_ERR_ARG;
+  if (!stream) return MTP_ERR_ARG;   // no context here: NULL is not mapped to anything (include/mtp_mi355x.h, "Streams")
   return mtp_launch_zero(d_p, (size_t) n, reinterpret_cast<hipStream_t>(stream)) == hipSuccess ? MTP_OK : MTP_ERR_DEVICE;
 }
 

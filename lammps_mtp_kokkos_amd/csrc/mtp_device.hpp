@@ -120,8 +120,12 @@ hipError_t mtp_launch_ev_finish_unpack(double *ev_slots, double *ev, int fold, d
 struct mtp_context;
 int mtp_internal_finish_unpack(mtp_context *c, void *stream, int eflag, int vflag, double *d_ev, double *d_f, const int *d_idx,
                                const double *d_frecv, int n3);
+// NULL -> the context's own stream; anything else unchanged (the one place the C ABI's NULL-stream rule is resolved)
+void *mtp_internal_resolve_stream(mtp_context *c, void *stream);
 hipError_t mtp_launch_fixed_to_force(long long *fq, double *f, int nall, hipStream_t st);
 hipError_t mtp_launch_zero(double *p, size_t n, hipStream_t st);
+// non-default compile-time tunables of mtp_kernels.hip, "NAME=value " each ("" for the shipped build)
+const char *mtp_kernel_build_flags();
 // radial block of cvec from dbasic (grade calls, after the force kernel)
 hipError_t mtp_launch_cvec_kernel(const MtpDevParams &p, int grid, int wpb, size_t lds, hipStream_t st);
 // grades[ilist[ii]] = max_r |sum_c cvec[ii][c] Ainv[r][c]| (f64 MFMA), running maximum into max_grade;
@@ -136,3 +140,8 @@ hipError_t mtp_launch_neighbor_build(const double *x, int inum, int nall, double
                                      const int ncell3[3], int *scratch, double *xs, void *cub_tmp, size_t cub_bytes, int *ilist,
                                      int *first, int *neigh, int *d_info, hipStream_t st);
 size_t mtp_neighbor_scan_bytes(int n, int nall);
+// LAMMPS-KOKKOS 2-D list view -> CSR (mtp_neighbor_kernels.hip): stage 1 (neigh == nullptr) counts and scans and
+// leaves {entries, longest row, bad-row flag} in d_info[3]; stage 2 fills neigh[]
+hipError_t mtp_launch_list_from_2d(int inum, const int *d_ilist, const int *d_numneigh, const int *d_neighbors,
+                                   long long stride_i, long long stride_jj, int cap, int *counts, void *cub_tmp,
+                                   size_t cub_bytes, int *first, int *neigh, int *d_info, hipStream_t st);

@@ -11,6 +11,15 @@
 // The exchange runs on the halo's own stream, tied to the caller's stream by events, so force work that needs no
 // ghosts (interior atoms) overlaps it (begin / end pairs).  Images of a rank's own atoms (periodic directions
 // with one rank) take the same path: a send to and a receive from itself inside the group.
+//
+// Streams: the halo calls have no context stream to fall back on, so a NULL `stream` is rejected (MTP_ERR_ARG);
+// mtp_halo_force_step, which has a context, resolves NULL to the context's stream ONCE and runs every piece of the
+// step -- pack, both groups, the force launch, the unpack -- on that one resolved stream.
+//
+// Without a communicator (mtp_halo_create with unique_id == NULL) a halo object still packs, unpacks and knows its
+// per-peer segment tables; mtp_halo_local_exchange() then moves the segments between the halo objects of ALL ranks of a
+// decomposition living in one process on one device (device-to-device copies driven by the same send / receive offset
+// tables the RCCL group uses) -- how the multi-peer indexing of an 8-rank job is exercised on a one-GPU box.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -124,34 +133,51 @@ int mtp_halo_get_unique_id(void *id_out)
   return MTP_OK;
 }
 
-int mtp_halo_create(int device_id, int nranks, int rank, const void *unique_id, int nlocal, int nghost,
-                    const int *send_idx, const double *send_shift, const int *send_counts, const int *recv_counts,
-                    mtp_halo **out, char *err, int errlen)
+// Host only: the per-peer segment tables of one rank -- send_off[q] / recv_off[q] = first atom of peer q's segment in
+// the packed send buffer / among the ghosts -- with every check mtp_halo_create makes on the layout contract.
+int mtp_halo_layout(int nranks, int nlocal, int nghost, const int *send_idx, const int *send_counts, const int *recv_counts,
+                    int *send_off, int *recv_off, char *err, int errlen)
 {
-  if (!out || !unique_id || nranks < 1 || rank < 0 || rank >= nranks || nlocal < 0 || nghost < 0 || !send_counts ||
-      !recv_counts)
-    return MTP_ERR_ARG;
-  *out = nullptr;
+  if (nranks < 1 || nlocal < 0 || nghost < 0 || !send_counts || !recv_counts) return MTP_ERR_ARG;
   long long nsend = 0, nrecv = 0;
   for (int q = 0; q < nranks; q++) {
     if (send_counts[q] < 0 || recv_counts[q] < 0) return MTP_ERR_ARG;
+    if (send_off) send_off[q] = (int) nsend;
+    if (recv_off) recv_off[q] = (int) nrecv;
     nsend += send_counts[q];
     nrecv += recv_counts[q];
+    if (3 * nsend > 0x7fffffffll || 3 * nrecv > 0x7fffffffll) {
+      copy_err("mtp_halo_create: more than 2^31-1 halo coordinates on one rank", err, errlen);
+      return MTP_ERR_LIMIT;
+    }
   }
+  if (send_off) send_off[nranks] = (int) nsend;
+  if (recv_off) recv_off[nranks] = (int) nrecv;
   if (nrecv != nghost) {
     copy_err("mtp_halo_create: recv_counts do not add up to nghost", err, errlen);
     return MTP_ERR_ARG;
   }
-  if (nsend > 0 && (!send_idx || !send_shift)) return MTP_ERR_ARG;
-  if (3 * nsend > 0x7fffffffll || 3ll * nghost > 0x7fffffffll) {
-    copy_err("mtp_halo_create: more than 2^31-1 halo coordinates on one rank", err, errlen);
-    return MTP_ERR_LIMIT;
-  }
+  if (nsend > 0 && !send_idx) return MTP_ERR_ARG;
   for (long long k = 0; k < nsend; k++)
     if (send_idx[k] < 0 || send_idx[k] >= nlocal) {   // checked on the host: the kernels index x and f with it
       copy_err("mtp_halo_create: send_idx outside the owned atoms", err, errlen);
       return MTP_ERR_ARG;
     }
+  return MTP_OK;
+}
+
+int mtp_halo_create(int device_id, int nranks, int rank, const void *unique_id, int nlocal, int nghost,
+                    const int *send_idx, const double *send_shift, const int *send_counts, const int *recv_counts,
+                    mtp_halo **out, char *err, int errlen)
+{
+  if (!out || nranks < 1 || rank < 0 || rank >= nranks || nlocal < 0 || nghost < 0 || !send_counts || !recv_counts)
+    return MTP_ERR_ARG;
+  *out = nullptr;
+  std::vector<int> soff((size_t) nranks + 1, 0), roff((size_t) nranks + 1, 0);
+  const int lrc = mtp_halo_layout(nranks, nlocal, nghost, send_idx, send_counts, recv_counts, soff.data(), roff.data(), err, errlen);
+  if (lrc != MTP_OK) return lrc;
+  const long long nsend = soff[nranks];
+  if (nsend > 0 && !send_shift) return MTP_ERR_ARG;
   mtp_halo *h = new (std::nothrow) mtp_halo();
   if (!h) return MTP_ERR_ARG;
   try {
@@ -167,12 +193,8 @@ int mtp_halo_create(int device_id, int nranks, int rank, const void *unique_id, 
     h->nsend = (int) nsend;
     h->send_counts.assign(send_counts, send_counts + nranks);
     h->recv_counts.assign(recv_counts, recv_counts + nranks);
-    h->send_off.assign((size_t) nranks + 1, 0);
-    h->recv_off.assign((size_t) nranks + 1, 0);
-    for (int q = 0; q < nranks; q++) {
-      h->send_off[q + 1] = h->send_off[q] + send_counts[q];
-      h->recv_off[q + 1] = h->recv_off[q] + recv_counts[q];
-    }
+    h->send_off = soff;
+    h->recv_off = roff;
     HIP_OK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
     if (const char *e = std::getenv("MTP_HALO_OVERLAP")) h->overlap = std::atoi(e) != 0;   // tuning default
     for (hipEvent_t *e : {&h->ev_fwd_ready, &h->ev_fwd_done, &h->ev_rev_ready, &h->ev_rev_done, &h->ev_red_ready,
@@ -187,13 +209,15 @@ int mtp_halo_create(int device_id, int nranks, int rank, const void *unique_id, 
       HIP_OK(hipMemcpy(h->d_send_idx, send_idx, (size_t) nsend * sizeof(int), hipMemcpyHostToDevice));
       HIP_OK(hipMemcpy(h->d_send_shift, send_shift, 3 * (size_t) nsend * sizeof(double), hipMemcpyHostToDevice));
     }
-    ncclUniqueId id;
-    std::memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
-    NCCL_OK(ncclCommInitRank(&h->comm, nranks, id, rank));
-    int cnt = 0, me = -1;
-    NCCL_OK(ncclCommCount(h->comm, &cnt));
-    NCCL_OK(ncclCommUserRank(h->comm, &me));
-    if (cnt != nranks || me != rank) throw HaloFail{"RCCL communicator disagrees with the requested rank layout"};
+    if (unique_id) {
+      ncclUniqueId id;
+      std::memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
+      NCCL_OK(ncclCommInitRank(&h->comm, nranks, id, rank));
+      int cnt = 0, me = -1;
+      NCCL_OK(ncclCommCount(h->comm, &cnt));
+      NCCL_OK(ncclCommUserRank(h->comm, &me));
+      if (cnt != nranks || me != rank) throw HaloFail{"RCCL communicator disagrees with the requested rank layout"};
+    }   // else: no communicator -- pack / unpack and mtp_halo_local_exchange only
   } catch (const HaloFail &f) {
     copy_err(f.what, err, errlen);
     delete h;
@@ -210,9 +234,9 @@ const char *mtp_halo_last_error(const mtp_halo *h) { return h ? h->last_error.c_
 int mtp_halo_comm_count(const mtp_halo *h, int *nranks, int *rank, int *rccl_version)
 {
   if (!h) return MTP_ERR_ARG;
-  int cnt = 0, me = 0, ver = 0;
-  if (ncclCommCount(h->comm, &cnt) != ncclSuccess || ncclCommUserRank(h->comm, &me) != ncclSuccess ||
-      ncclGetVersion(&ver) != ncclSuccess)
+  int cnt = h->nranks, me = h->rank, ver = 0;
+  if (ncclGetVersion(&ver) != ncclSuccess) return MTP_ERR_DEVICE;
+  if (h->comm && (ncclCommCount(h->comm, &cnt) != ncclSuccess || ncclCommUserRank(h->comm, &me) != ncclSuccess))
     return MTP_ERR_DEVICE;
   if (nranks) *nranks = cnt;
   if (rank) *rank = me;
@@ -220,35 +244,63 @@ int mtp_halo_comm_count(const mtp_halo *h, int *nranks, int *rank, int *rccl_ver
   return MTP_OK;
 }
 
-// One grouped exchange on the halo's stream: to every peer `sbuf + 3 soff[q]` (scount[q] atoms), from every peer
-// into `rbuf + 3 roff[q]` (rcount[q] atoms).
+// One grouped exchange on stream `st`: to every peer `sbuf + 3 soff[q]` (scount[q] atoms), from every peer
+// into `rbuf + 3 roff[q]` (rcount[q] atoms).  A failing ncclSend / ncclRecv still closes the group (an open group
+// would swallow every later RCCL call of the process).
 static void exchange(mtp_halo *h, const double *sbuf, const std::vector<int> &soff, const std::vector<int> &scount,
-                     double *rbuf, const std::vector<int> &roff, const std::vector<int> &rcount, hipStream_t on = nullptr)
+                     double *rbuf, const std::vector<int> &roff, const std::vector<int> &rcount, hipStream_t st)
 {
-  const hipStream_t st = on ? on : h->comm_stream;
+  if (!h->comm) throw HaloFail{"this halo was created without a communicator (unique_id == NULL): use mtp_halo_local_exchange"};
   NCCL_OK(ncclGroupStart());
-  for (int q = 0; q < h->nranks; q++) {
-    if (scount[q] > 0) NCCL_OK(ncclSend(sbuf + 3 * (size_t) soff[q], 3 * (size_t) scount[q], ncclDouble, q, h->comm, st));
-    if (rcount[q] > 0) NCCL_OK(ncclRecv(rbuf + 3 * (size_t) roff[q], 3 * (size_t) rcount[q], ncclDouble, q, h->comm, st));
+  ncclResult_t bad = ncclSuccess;
+  for (int q = 0; q < h->nranks && bad == ncclSuccess; q++) {
+    if (scount[q] > 0) bad = ncclSend(sbuf + 3 * (size_t) soff[q], 3 * (size_t) scount[q], ncclDouble, q, h->comm, st);
+    if (bad == ncclSuccess && rcount[q] > 0)
+      bad = ncclRecv(rbuf + 3 * (size_t) roff[q], 3 * (size_t) rcount[q], ncclDouble, q, h->comm, st);
   }
-  NCCL_OK(ncclGroupEnd());
+  const ncclResult_t end = ncclGroupEnd();
+  if (bad != ncclSuccess) throw HaloFail{std::string("ncclSend / ncclRecv: ") + ncclGetErrorString(bad)};
+  if (end != ncclSuccess) throw HaloFail{std::string("ncclGroupEnd: ") + ncclGetErrorString(end)};
+}
+
+static void pack_forward(mtp_halo *h, hipStream_t st, const double *d_x)
+{
+  if (h->nsend > 0) {
+    const int n3 = 3 * h->nsend;
+    hipLaunchKernelGGL(halo_pack_kernel, dim3((n3 + 255) / 256), dim3(256), 0, st, d_x, h->d_send_idx, h->d_send_shift,
+                       h->d_sendbuf, n3);
+    HIP_OK(hipGetLastError());
+  }
+}
+
+static void unpack_reverse(mtp_halo *h, hipStream_t st, double *d_f)
+{
+  if (h->nsend > 0) {
+    const int n3 = 3 * h->nsend;
+    hipLaunchKernelGGL(halo_unpack_add_kernel, dim3((n3 + 255) / 256), dim3(256), 0, st, d_f, h->d_send_idx, h->d_frecv, n3);
+    HIP_OK(hipGetLastError());
+  }
+}
+
+static int null_stream(mtp_halo *h, const char *fn)
+{
+  h->last_error = std::string(fn) + ": a NULL stream is not accepted (the halo has no stream of its own to order the "
+                                    "caller's work on; pass the stream the surrounding kernels run on)";
+  return MTP_ERR_ARG;
 }
 
 int mtp_halo_forward_begin(mtp_halo *h, void *stream, double *d_x)
 {
   if (!h || !d_x) return MTP_ERR_ARG;
+  if (!stream) return null_stream(h, "mtp_halo_forward_begin");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   try {
     HIP_OK(hipSetDevice(h->device));
-    if (h->nsend > 0) {
-      const int n3 = 3 * h->nsend;
-      hipLaunchKernelGGL(halo_pack_kernel, dim3((n3 + 255) / 256), dim3(256), 0, st, d_x, h->d_send_idx,
-                         h->d_send_shift, h->d_sendbuf, n3);
-      HIP_OK(hipGetLastError());
-    }
+    pack_forward(h, st, d_x);
     HIP_OK(hipEventRecord(h->ev_fwd_ready, st));
     HIP_OK(hipStreamWaitEvent(h->comm_stream, h->ev_fwd_ready, 0));
-    exchange(h, h->d_sendbuf, h->send_off, h->send_counts, d_x + 3 * (size_t) h->nlocal, h->recv_off, h->recv_counts);
+    exchange(h, h->d_sendbuf, h->send_off, h->send_counts, d_x + 3 * (size_t) h->nlocal, h->recv_off, h->recv_counts,
+             h->comm_stream);
     HIP_OK(hipEventRecord(h->ev_fwd_done, h->comm_stream));
   } catch (const HaloFail &f) {
     h->last_error = f.what;
@@ -260,7 +312,9 @@ int mtp_halo_forward_begin(mtp_halo *h, void *stream, double *d_x)
 int mtp_halo_forward_end(mtp_halo *h, void *stream)
 {
   if (!h) return MTP_ERR_ARG;
-  if (hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), h->ev_fwd_done, 0) != hipSuccess) {
+  if (!stream) return null_stream(h, "mtp_halo_forward_end");
+  if (hipSetDevice(h->device) != hipSuccess ||
+      hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), h->ev_fwd_done, 0) != hipSuccess) {
     h->last_error = "hipStreamWaitEvent failed (forward halo)";
     return MTP_ERR_DEVICE;
   }
@@ -270,13 +324,15 @@ int mtp_halo_forward_end(mtp_halo *h, void *stream)
 int mtp_halo_reverse_begin(mtp_halo *h, void *stream, const double *d_f)
 {
   if (!h || !d_f) return MTP_ERR_ARG;
+  if (!stream) return null_stream(h, "mtp_halo_reverse_begin");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   try {
     HIP_OK(hipSetDevice(h->device));
     HIP_OK(hipEventRecord(h->ev_rev_ready, st));
     HIP_OK(hipStreamWaitEvent(h->comm_stream, h->ev_rev_ready, 0));
     // the ghost rows of f go back the way the ghost positions came: sizes and peers swap roles
-    exchange(h, d_f + 3 * (size_t) h->nlocal, h->recv_off, h->recv_counts, h->d_frecv, h->send_off, h->send_counts);
+    exchange(h, d_f + 3 * (size_t) h->nlocal, h->recv_off, h->recv_counts, h->d_frecv, h->send_off, h->send_counts,
+             h->comm_stream);
     HIP_OK(hipEventRecord(h->ev_rev_done, h->comm_stream));
   } catch (const HaloFail &f) {
     h->last_error = f.what;
@@ -288,15 +344,12 @@ int mtp_halo_reverse_begin(mtp_halo *h, void *stream, const double *d_f)
 int mtp_halo_reverse_end(mtp_halo *h, void *stream, double *d_f)
 {
   if (!h || !d_f) return MTP_ERR_ARG;
+  if (!stream) return null_stream(h, "mtp_halo_reverse_end");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   try {
+    HIP_OK(hipSetDevice(h->device));
     HIP_OK(hipStreamWaitEvent(st, h->ev_rev_done, 0));
-    if (h->nsend > 0) {
-      const int n3 = 3 * h->nsend;
-      hipLaunchKernelGGL(halo_unpack_add_kernel, dim3((n3 + 255) / 256), dim3(256), 0, st, d_f, h->d_send_idx,
-                         h->d_frecv, n3);
-      HIP_OK(hipGetLastError());
-    }
+    unpack_reverse(h, st, d_f);
   } catch (const HaloFail &f) {
     h->last_error = f.what;
     return MTP_ERR_DEVICE;
@@ -316,75 +369,163 @@ int mtp_halo_reverse(mtp_halo *h, void *stream, double *d_f)
   return rc != MTP_OK ? rc : mtp_halo_reverse_end(h, stream, d_f);
 }
 
-// One domain-decomposed force call with both exchanges overlapped (rows of the installed list ordered interior A |
-// boundary | interior C): zero f; forward halo || rows A; boundary rows; reverse halo || rows C; fold.  One entry
-// point instead of eight, so a driver's per-call overhead is paid once per step.
+// One domain-decomposed force call (one entry point instead of eight, so a driver's per-call overhead is paid once
+// per step).  Once the forward exchange has been issued the reverse exchange is ALWAYS issued too, whatever the
+// force launches returned: a rank that skipped it would leave its peers blocked in their ncclRecv.  The first error
+// is returned afterwards.
 int mtp_halo_force_step(mtp_halo *h, mtp_context *ctx, void *stream, int rows_a, int rows_b, int rows_c, double *d_x,
                         const int *d_type, int eflag, int vflag, int grade_flag, double *d_f, double *d_eatom,
                         double *d_vatom, double *d_ev, double *d_grades, double *d_max_grade, double *d_coeff_ders)
 {
   if (!h || !ctx || !d_x || !d_f || rows_a < 0 || rows_b < 0 || rows_c < 0) return MTP_ERR_ARG;
   if (reinterpret_cast<uintptr_t>(d_f) & 15u) return MTP_ERR_ARG;
+  // NULL -> the context's stream, resolved once: every launch and both groups below use `sv`
+  void *sv = mtp_internal_resolve_stream(ctx, stream);
+  hipStream_t st = reinterpret_cast<hipStream_t>(sv);
   int rc = MTP_OK;
-  if (!h->overlap) {
-    // Default: everything on the caller's stream -- zero + pack, forward group, ONE launch over all rows, reverse group,
-    // unpack.  Nothing overlaps, but there is no cross-stream hand-over (6-7 us each on this stack, four per step) and
-    // the rows are not split into three launches that each cost a round of wavefronts: measured with the self-exchange
-    // 0.097 vs 0.129 ms at 8 192 atoms and 0.507 vs 0.545 ms at 65 536 (mtp_halo_set_overlap(1) selects the other path).
-    try {
-      hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-      HIP_OK(hipSetDevice(h->device));
-      const int n3 = 3 * h->nsend;
-      const size_t nz = 3 * (size_t) (h->nlocal + h->nghost), work = std::max<size_t>((size_t) n3, (nz + 1) / 2);
-      if (work > 0) {
-        hipLaunchKernelGGL(halo_pack_zero_kernel, dim3((unsigned) ((work + 255) / 256)), dim3(256), 0, st, d_x, h->d_send_idx,
-                           h->d_send_shift, h->d_sendbuf, n3, d_f, nz);
-        HIP_OK(hipGetLastError());
-      }
-      exchange(h, h->d_sendbuf, h->send_off, h->send_counts, d_x + 3 * (size_t) h->nlocal, h->recv_off, h->recv_counts, st);
-      // (finish_tallies = 0: the tally fold rides in the unpack launch behind the reverse exchange)
-      rc = mtp_compute_device_rows(ctx, stream, 0, rows_a + rows_b + rows_c, 0, d_x, d_type, eflag, vflag, grade_flag, d_f,
-                                   d_eatom, d_vatom, d_ev, d_grades, d_max_grade, d_coeff_ders);
-      exchange(h, d_f + 3 * (size_t) h->nlocal, h->recv_off, h->recv_counts, h->d_frecv, h->send_off, h->send_counts, st);
-      const int rc2 = mtp_internal_finish_unpack(ctx, stream, eflag, vflag, d_ev, d_f, h->d_send_idx, h->d_frecv, n3);
-      if (rc == MTP_OK) rc = rc2;
-    } catch (const HaloFail &f) {
-      h->last_error = f.what;
-      return MTP_ERR_DEVICE;
-    }
-    return rc;
-  }
-  try {   // forward_begin with the zeroing of f folded into the pack launch
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  auto keep = [&](int r) {
+    if (rc == MTP_OK) rc = r;
+  };
+  const int n3 = 3 * h->nsend;
+  const size_t nz = 3 * (size_t) (h->nlocal + h->nghost), work = std::max<size_t>((size_t) n3, (nz + 1) / 2);
+  bool forward_issued = false;
+  try {
     HIP_OK(hipSetDevice(h->device));
-    const int n3 = 3 * h->nsend;
-    const size_t nz = 3 * (size_t) (h->nlocal + h->nghost), work = std::max<size_t>((size_t) n3, (nz + 1) / 2);
-    if (work > 0) {
+    if (work > 0) {   // zero f + pack: one launch
       hipLaunchKernelGGL(halo_pack_zero_kernel, dim3((unsigned) ((work + 255) / 256)), dim3(256), 0, st, d_x, h->d_send_idx,
                          h->d_send_shift, h->d_sendbuf, n3, d_f, nz);
       HIP_OK(hipGetLastError());
     }
+    if (!h->overlap) {
+      // Default: everything on the one stream -- zero + pack, forward group, ONE launch over all rows, reverse group,
+      // unpack.  Nothing overlaps, but there is no cross-stream hand-over (6-7 us each on this stack, four per step) and
+      // the rows are not split into three launches that each cost a round of wavefronts: measured with the self-exchange
+      // 0.097 vs 0.129 ms at 8 192 atoms and 0.507 vs 0.545 ms at 65 536 (mtp_halo_set_overlap(1) selects the other path).
+      exchange(h, h->d_sendbuf, h->send_off, h->send_counts, d_x + 3 * (size_t) h->nlocal, h->recv_off, h->recv_counts, st);
+      forward_issued = true;
+      // (finish_tallies = 0: the tally fold rides in the unpack launch behind the reverse exchange)
+      keep(mtp_compute_device_rows(ctx, sv, 0, rows_a + rows_b + rows_c, 0, d_x, d_type, eflag, vflag, grade_flag, d_f,
+                                   d_eatom, d_vatom, d_ev, d_grades, d_max_grade, d_coeff_ders));
+      exchange(h, d_f + 3 * (size_t) h->nlocal, h->recv_off, h->recv_counts, h->d_frecv, h->send_off, h->send_counts, st);
+      keep(mtp_internal_finish_unpack(ctx, sv, eflag, vflag, d_ev, d_f, h->d_send_idx, h->d_frecv, n3));
+      return rc;
+    }
+    // Overlapped (rows of the installed list ordered interior A | boundary | interior C): forward halo || rows A;
+    // boundary rows; reverse halo || rows C; unpack; the groups on the halo's own stream, tied to `st` by events.
     HIP_OK(hipEventRecord(h->ev_fwd_ready, st));
     HIP_OK(hipStreamWaitEvent(h->comm_stream, h->ev_fwd_ready, 0));
-    exchange(h, h->d_sendbuf, h->send_off, h->send_counts, d_x + 3 * (size_t) h->nlocal, h->recv_off, h->recv_counts);
+    exchange(h, h->d_sendbuf, h->send_off, h->send_counts, d_x + 3 * (size_t) h->nlocal, h->recv_off, h->recv_counts,
+             h->comm_stream);
+    forward_issued = true;
     HIP_OK(hipEventRecord(h->ev_fwd_done, h->comm_stream));
+    if (rows_a > 0)
+      keep(mtp_compute_device_rows(ctx, sv, 0, rows_a, 0, d_x, d_type, eflag, vflag, grade_flag, d_f, d_eatom, d_vatom,
+                                   d_ev, d_grades, d_max_grade, d_coeff_ders));
+    HIP_OK(hipStreamWaitEvent(st, h->ev_fwd_done, 0));
+    if (rc == MTP_OK)
+      keep(mtp_compute_device_rows(ctx, sv, rows_a, rows_b, rows_c == 0, d_x, d_type, eflag, vflag, grade_flag, d_f,
+                                   d_eatom, d_vatom, d_ev, d_grades, d_max_grade, d_coeff_ders));
+    keep(mtp_halo_reverse_begin(h, sv, d_f));   // even after a failed launch: the peers wait for it
+    if (rc == MTP_OK && rows_c > 0)
+      keep(mtp_compute_device_rows(ctx, sv, rows_a + rows_b, rows_c, 1, d_x, d_type, eflag, vflag, grade_flag, d_f,
+                                   d_eatom, d_vatom, d_ev, d_grades, d_max_grade, d_coeff_ders));
+    keep(mtp_halo_reverse_end(h, sv, d_f));
+  } catch (const HaloFail &f) {
+    h->last_error = f.what;
+    // a HIP failure between the two exchanges: still try to meet the peers' receives before reporting it
+    if (forward_issued && h->comm) {
+      try {
+        exchange(h, d_f + 3 * (size_t) h->nlocal, h->recv_off, h->recv_counts, h->d_frecv, h->send_off, h->send_counts,
+                 h->overlap ? h->comm_stream : st);
+      } catch (const HaloFail &) {
+      }
+    }
+    return MTP_ERR_DEVICE;
+  }
+  return rc;
+}
+
+// The two kernels either side of an exchange, on their own (drivers that move the segments themselves, and the
+// single-process rehearsal below): sendbuf[k] = x[send_idx[k]] + shift[k]   /   f[send_idx[k]] += frecv[k].
+int mtp_halo_pack_forward(mtp_halo *h, void *stream, const double *d_x)
+{
+  if (!h || !d_x) return MTP_ERR_ARG;
+  if (!stream) return null_stream(h, "mtp_halo_pack_forward");
+  try {
+    HIP_OK(hipSetDevice(h->device));
+    pack_forward(h, reinterpret_cast<hipStream_t>(stream), d_x);
   } catch (const HaloFail &f) {
     h->last_error = f.what;
     return MTP_ERR_DEVICE;
   }
-  if (rc == MTP_OK && rows_a > 0)
-    rc = mtp_compute_device_rows(ctx, stream, 0, rows_a, 0, d_x, d_type, eflag, vflag, grade_flag, d_f, d_eatom, d_vatom,
-                                 d_ev, d_grades, d_max_grade, d_coeff_ders);
-  if (rc == MTP_OK) rc = mtp_halo_forward_end(h, stream);
-  if (rc == MTP_OK)
-    rc = mtp_compute_device_rows(ctx, stream, rows_a, rows_b, rows_c == 0, d_x, d_type, eflag, vflag, grade_flag, d_f,
-                                 d_eatom, d_vatom, d_ev, d_grades, d_max_grade, d_coeff_ders);
-  if (rc == MTP_OK) rc = mtp_halo_reverse_begin(h, stream, d_f);
-  if (rc == MTP_OK && rows_c > 0)
-    rc = mtp_compute_device_rows(ctx, stream, rows_a + rows_b, rows_c, 1, d_x, d_type, eflag, vflag, grade_flag, d_f,
-                                 d_eatom, d_vatom, d_ev, d_grades, d_max_grade, d_coeff_ders);
-  if (rc == MTP_OK) rc = mtp_halo_reverse_end(h, stream, d_f);
-  return rc;
+  return MTP_OK;
+}
+
+int mtp_halo_unpack_reverse(mtp_halo *h, void *stream, double *d_f)
+{
+  if (!h || !d_f) return MTP_ERR_ARG;
+  if (!stream) return null_stream(h, "mtp_halo_unpack_reverse");
+  try {
+    HIP_OK(hipSetDevice(h->device));
+    unpack_reverse(h, reinterpret_cast<hipStream_t>(stream), d_f);
+  } catch (const HaloFail &f) {
+    h->last_error = f.what;
+    return MTP_ERR_DEVICE;
+  }
+  return MTP_OK;
+}
+
+int mtp_halo_get_layout(const mtp_halo *h, int *nsend, int *send_off, int *send_counts, int *recv_off, int *recv_counts)
+{
+  if (!h) return MTP_ERR_ARG;
+  if (nsend) *nsend = h->nsend;
+  for (int q = 0; q <= h->nranks; q++) {
+    if (send_off) send_off[q] = h->send_off[q];
+    if (recv_off) recv_off[q] = h->recv_off[q];
+    if (q < h->nranks && send_counts) send_counts[q] = h->send_counts[q];
+    if (q < h->nranks && recv_counts) recv_counts[q] = h->recv_counts[q];
+  }
+  return MTP_OK;
+}
+
+// What the RCCL groups of all ranks do together, for the n = nranks halo objects of one decomposition living in one
+// process on one device: direction 0 (forward) copies, for every pair (r, q), rank q's packed segment for r --
+// sendbuf_q + 3 send_off_q[r], send_counts_q[r] atoms -- into r's ghost rows d_arrays[r] + 3 (nlocal_r + recv_off_r[q]);
+// direction 1 (reverse) copies r's ghost rows of d_arrays[r] (forces) for q back into frecv_q + 3 send_off_q[r].  The
+// per-peer offsets are the ones exchange() hands to ncclSend / ncclRecv; the counts of the two sides must agree.
+int mtp_halo_local_exchange(mtp_halo *const *halos, int n, void *stream, int direction, double *const *d_arrays)
+{
+  if (!halos || n < 1 || !d_arrays || (direction != 0 && direction != 1)) return MTP_ERR_ARG;
+  for (int r = 0; r < n; r++)
+    if (!halos[r] || !d_arrays[r] || halos[r]->nranks != n || halos[r]->rank != r || halos[r]->device != halos[0]->device) {
+      if (halos[0]) halos[0]->last_error = "mtp_halo_local_exchange: halos must be ranks 0..n-1 of one n-rank decomposition on one device";
+      return MTP_ERR_ARG;
+    }
+  mtp_halo *h0 = halos[0];
+  if (!stream) return null_stream(h0, "mtp_halo_local_exchange");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  try {
+    HIP_OK(hipSetDevice(h0->device));
+    for (int r = 0; r < n; r++)
+      for (int q = 0; q < n; q++) {
+        const mtp_halo *hr = halos[r], *hq = halos[q];
+        const int cnt = hr->recv_counts[q];
+        if (cnt != hq->send_counts[r]) throw HaloFail{"mtp_halo_local_exchange: rank " + std::to_string(q) + " sends " +
+                                                      std::to_string(hq->send_counts[r]) + " atoms to rank " + std::to_string(r) +
+                                                      ", which expects " + std::to_string(cnt)};
+        if (cnt == 0) continue;
+        double *ghost_rows = d_arrays[r] + 3 * ((size_t) hr->nlocal + (size_t) hr->recv_off[q]);
+        const size_t bytes = 3 * (size_t) cnt * sizeof(double);
+        if (direction == 0)
+          HIP_OK(hipMemcpyAsync(ghost_rows, hq->d_sendbuf + 3 * (size_t) hq->send_off[r], bytes, hipMemcpyDeviceToDevice, st));
+        else
+          HIP_OK(hipMemcpyAsync(hq->d_frecv + 3 * (size_t) hq->send_off[r], ghost_rows, bytes, hipMemcpyDeviceToDevice, st));
+      }
+  } catch (const HaloFail &f) {
+    h0->last_error = f.what;
+    return MTP_ERR_DEVICE;
+  }
+  return MTP_OK;
 }
 
 int mtp_halo_set_overlap(mtp_halo *h, int enable)
@@ -400,6 +541,11 @@ int mtp_halo_allreduce(mtp_halo *h, void *stream, double *d_buf, int count, int 
 {
   if (!h || !d_buf || count < 0 || (op != MTP_REDUCE_SUM && op != MTP_REDUCE_MAX)) return MTP_ERR_ARG;
   if (count == 0) return MTP_OK;
+  if (!stream) return null_stream(h, "mtp_halo_allreduce");
+  if (!h->comm) {
+    h->last_error = "mtp_halo_allreduce: this halo was created without a communicator";
+    return MTP_ERR_STATE;
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   try {
     HIP_OK(hipSetDevice(h->device));

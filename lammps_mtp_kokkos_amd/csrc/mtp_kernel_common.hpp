@@ -112,11 +112,7 @@ static __device__ __forceinline__ double wave_sum(double v)   // same bits in ev
 
 static __device__ __forceinline__ void lds_add(double *p, double v)
 {
-#ifdef MTP_EXP_NOATOM   // timing experiment only (wrong results): plain store instead of ds_add_f64
-  *p = v;
-#else
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
 }
 
 // LDS read at (32-bit LDS byte address + compile-time byte offset): the offset lands in the

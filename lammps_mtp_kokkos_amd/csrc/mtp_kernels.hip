@@ -49,24 +49,8 @@ namespace {
 // cache that the compiler re-issues where a field is needed) instead of a by-value struct, which it kept in SGPRs
 // across the whole atom loop and spilled into VGPR lanes (a quarter of the static VALU instructions were
 // v_readlane / v_writelane, 255 VGPRs; now 229 and none).  Making the pointer opaque again at every phase boundary
-// (MTP_KP_FRESH) was measured 1 % slower.
+// was measured 1 % slower.
 typedef const __attribute__((address_space(4))) MtpDevParams *KP;
-#ifdef MTP_EXP_SCALARS_LDS_ONLY   // timing experiment
-#define MTP_SCALARS_COND true
-#else
-#define MTP_SCALARS_COND kp->scalars_in_lds
-#endif
-#ifdef MTP_KP_FRESH
-static __device__ __forceinline__ KP kp_fresh()
-{
-  KP k = (KP) __builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(k));
-  return k;
-}
-#define KP_FRESH() kp = kp_fresh()
-#else
-#define KP_FRESH() ((void) 0)
-#endif
 
 // f[idx] += v.  Default: native fp64 HBM atomics (the sum depends on the arrival order in the last bits).
 // Deterministic mode (mtp_context_set_deterministic, tests / reproducible goldens): the contributions are added as
@@ -321,13 +305,9 @@ __device__ __forceinline__ void products_forward(const MtpRow8 *rows, const int 
       for (int u = 0; u < U; u++) rw[u] = rp[64 * min(it + u, nit - 1)];   // uniform clamp: the tail re-reads the last block
 #pragma unroll
       for (int u = 0; u < U; u++) v[u] = M[rw[u].lo & 0xffffu] * M[rw[u].lo >> 16];
-#ifdef MTP_EXP_GATHER_EMU   // timing experiment (wrong results): one add per four rows, as a target-sorted gather would issue
-      if (it < nit) lds_add(&M[rw[0].hi & 0xffffu], (double) ((int) rw[0].hi >> 16) * (v[0] + v[1] + v[2] + v[3]));
-#else
 #pragma unroll
       for (int u = 0; u < U; u++)
         if (it + u < nit) lds_add(&M[rw[u].hi & 0xffffu], (double) ((int) rw[u].hi >> 16) * v[u]);   // uniform branch
-#endif
     }
     wave_fence();
   }
@@ -353,24 +333,12 @@ __device__ __forceinline__ void products_backward(const MtpRow8 *rows, const int
         m0[u] = M[rw[u].lo & 0xffffu];
         m1[u] = M[rw[u].lo >> 16];
       }
-#ifdef MTP_EXP_GATHER_EMU   // timing experiment (wrong results): four reads per row, two adds per four rows
-      {
-        double x4 = 0.0;
-#pragma unroll
-        for (int u = 0; u < U; u++) x4 += D[rw[u].lo & 0xffffu];
-        if (it < nit) {
-          lds_add(&D[rw[0].lo >> 16], d3[0] * m0[0] + d3[1] * m0[1] + x4);
-          lds_add(&D[rw[0].lo & 0xffffu], d3[2] * m1[2] + d3[3] * m1[3]);
-        }
-      }
-#else
 #pragma unroll
       for (int u = 0; u < U; u++)
         if (it + u < nit) {
           lds_add(&D[rw[u].lo >> 16], d3[u] * m0[u]);
           lds_add(&D[rw[u].lo & 0xffffu], d3[u] * m1[u]);
         }
-#endif
     }
     wave_fence();
   }
@@ -673,11 +641,7 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
   // Product passes: the wide lane grids (KL = 64: level 18 and up, thousands of times rows that live in HBM / L2 either
   // way) run the gather programs -- measured at level 20: 2.02 -> 1.93 ms; the narrow grids keep the row-per-lane passes
   // with the rows in LDS -- at level 16 the gather programs (27 KB, so in L2) were 2.3 % slower (0.523 vs 0.511 ms).
-#ifdef MTP_GATHER_ALL      // diagnostic builds: gather passes for every lane grid
-  constexpr bool GATHER = true;
-#else
   constexpr bool GATHER = KL == 64;
-#endif
   constexpr int NG = 64 / KL;            // neighbour groups in the wavefront
   constexpr int NPG = NT / NG;           // neighbours per group per tile
   static_assert(NT == 32, "the force phase maps lanes to (32 neighbours) x (2 halves)");
@@ -755,13 +719,8 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
   double vacc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, eacc = 0.0;
   // (Only in the 2-per-SIMD build: at 168 VGPRs the seven extra accumulators spill and cost more than the per-atom
   // reductions -- measured 0.514 against 0.500 ms.)
-#ifdef MTP_DEFER3   // timing experiment: deferred tallies in the 3-per-SIMD build too
-  const bool v_per_atom = (kp->vflag & 4) != 0;
-  const bool e_per_atom = (kp->eflag & 2) != 0;
-#else
   const bool v_per_atom = WPS == 3 ? kp->vflag != 0 : (kp->vflag & 4) != 0;
   const bool e_per_atom = WPS == 3 ? true : (kp->eflag & 2) != 0;
-#endif
 #ifdef MTP_STAMPS
   unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_prev = __builtin_amdgcn_s_memtime();
@@ -803,7 +762,6 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     const int jnum = __builtin_amdgcn_readfirstlane(kp->first[ii + 1]) - jbeg;
 
     STAMP(0);   // loop head: ilist/type/x/first loads issue
-    KP_FRESH();
     // ---- 1. compaction (the first NT survivors go straight into the tile arrays) --------
     int cnt = 0;
     const int cj_last = kp->cj_cap - 1;
@@ -879,7 +837,6 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     wave_fence();
 
     STAMP(1);   // compaction
-    KP_FRESH();
     // ---- 2+3. tiles: tables, then basic moments in registers ------------------------------
     double acc[NB][9];
 #pragma unroll
@@ -898,7 +855,6 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, tile > 0, true, kp->dg_mode == 0, kp->dg_mode == 1, park, xi0, xi1, xi2, i,
                         itype, lane);
       STAMP(2);   // tile tables
-    KP_FRESH();
 #pragma unroll
       for (int m = 0; m < NPG; m++) {
         if (m * NG < ntp) {
@@ -932,7 +888,6 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       if (ntiles > 1) wave_fence();
     }
     STAMP(3);   // basic moments
-    KP_FRESH();
     // sum over the neighbour groups, then moments + adjoints into LDS
 #pragma unroll
     for (int t = 0; t < NB; t++)
@@ -959,32 +914,27 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     wave_fence();
 
     // ---- 4a. products, level by level (pair_mtp.cpp:196-201) -----------------------------
-#ifndef MTP_EXP_NOPRODUCTS   // timing / counter experiment only (wrong results)
     if constexpr (GATHER) {
       gather_pass(kp->prog_fwd, bt.seg_fwd, kp->nlevels, w.M, w.M, w.M, lane);
     } else {
       if (rows_lds) products_forward<MTP_PU>(bt.rows, bt.level, kp->nlevels, w.M, lane);
       else products_forward<MTP_PU>(kp->rows, bt.level, kp->nlevels, w.M, lane);
     }
-#endif
     // ---- site energy (pair_mtp.cpp:204-212): the leaf rows' share first ------------------------------------
     double e = 0.0;
     // (two code paths per table home, LDS blob or HBM/L2: no pointer selects between address spaces, see below)
     const int leaf_beg = __builtin_amdgcn_readfirstlane(bt.level[kp->nlevels]);
     const int leaf_nit = (__builtin_amdgcn_readfirstlane(bt.level[kp->nlevels + 1]) - leaf_beg) >> 6;
-#ifndef MTP_EXP_NOPRODUCTS
     if (rows_lds) e = leaf_forward<MTP_PU, GRADE, false>(bt.rows, bt.leaf_cf, leaf_beg, leaf_nit, w.M, lane);
     else e = leaf_forward<MTP_PU, GRADE, true>(kp->rows, kp->leaf_cf, leaf_beg, leaf_nit, w.M, lane);
-#endif
     STAMP(4);   // products forward
-    KP_FRESH();
     // ---- candidate vector, species and linear blocks (pair_mtp_extrapolation.cpp:235-252) ----
     if (GRADE) {
       double *crow = kp->cvec + (size_t) ii * kp->cpad + kp->Sp * kp->Sp * kp->Mu * kp->R;
       for (int k = lane; k < kp->Sp; k += 64) crow[k] = k == itype ? 1.0 : 0.0;
       for (int k = lane; k < kp->S; k += 64) crow[kp->Sp + k] = w.M[kp->g_map_all[k]];
     }
-    if (MTP_SCALARS_COND)
+    if (kp->scalars_in_lds)
       for (int k = lane; k < kp->Se; k += 64) e += bt.lin[k] * w.M[bt.map[k]];
     else
       for (int k = lane; k < kp->Se; k += 64) e += kp->g_lin[k] * w.M[kp->g_map[k]];
@@ -998,14 +948,12 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       eacc += e + (lane == 0 ? kp->species_coeffs[itype] : 0.0);
     }
     // ---- 4b. adjoints (pair_mtp.cpp:217-233) ----------------------------------------------
-    if (MTP_SCALARS_COND)
+    if (kp->scalars_in_lds)
       for (int k = lane; k < kp->nseed; k += 64) w.D[bt.seed_idx[k]] = bt.seed_val[k];
     else
       for (int k = lane; k < kp->nseed; k += 64) w.D[kp->g_seed_idx[k]] = kp->g_seed_val[k];
     wave_fence();
     STAMP(5);   // energy + seeds
-    KP_FRESH();
-#ifndef MTP_EXP_NOPRODUCTS
     if (rows_lds) leaf_backward<MTP_PU, false>(bt.rows, bt.leaf_cb, leaf_beg, leaf_nit, w.M, w.D, lane);
     else leaf_backward<MTP_PU, true>(kp->rows, kp->leaf_cb, leaf_beg, leaf_nit, w.M, w.D, lane);
     if constexpr (GATHER) {
@@ -1014,10 +962,8 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       if (rows_lds) products_backward<MTP_PU>(bt.rows, bt.level, kp->nlevels, w.M, w.D, lane);
       else products_backward<MTP_PU>(kp->rows, bt.level, kp->nlevels, w.M, w.D, lane);
     }
-#endif
 
     STAMP(6);   // products backward
-    KP_FRESH();
     // ---- 5. forces ---------------------------------------------------------------------------
     // the (now free) moment region receives the coefficient blocks of the derivative polynomials:
     // basic k = (slot s; a, b, c) puts a D_k at the d/dx coefficient of x^(a-1) y^b z^c, b D_k and c D_k alike
@@ -1054,7 +1000,6 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     }
     wave_fence();
     STAMP(9);   // coefficient blocks
-    KP_FRESH();
     {
       const int n = lane & 31, part = lane >> 5;
       unsigned pcol = w.addr(w.tab + n);
@@ -1121,12 +1066,8 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
         const double Fx = part ? 0.0 : Fa, Fz = part ? Fa : 0.0;
         if (valid) {
           const size_t j = (size_t) w.nbj[n];
-#ifndef MTP_EXP_NOSCATTER   // timing experiment only (wrong results)
           force_add(kp, 3 * j + (part ? 2 : 0), -Fa);   // pair_mtp.cpp:252-254
           if (part == 0) force_add(kp, 3 * j + 1, -Fy);
-#else
-          if (Fa + Fy == 12345.678) kp->f[3 * j] = Fa;   // keeps the values live
-#endif
         }
         // ---- totals of this tile over the 64 lanes: force on i (3), virial (6); lane v < 9 ends up with value v.
         // Per tile, not per atom: nine running sums carried across the tile loop would be live through the whole
@@ -1186,10 +1127,8 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       }
     }
     STAMP(7);   // forces
-    KP_FRESH();
     wave_fence();
     STAMP(8);   // per-atom totals
-    KP_FRESH();
   }
 #ifdef MTP_STAMPS
   if (lane == 0 && kp->stamps)
@@ -1643,16 +1582,12 @@ hipError_t mtp_launch_wave_kernel(const MtpDevParams &p, int grid, int wpb, size
   if (wpb < 1 || wpb > (p.wps == 3 ? 12 : 8)) return hipErrorInvalidValue;
 #define MTP_CASE(kl, nb) \
   if (KL == kl && NB == nb) return launch_pitch<kl, nb>(p, grid, wpb, lds, st);
-#ifndef MTP_EXP_ONLY_KL32   // (compile-time experiments: only the level-16 lane grid)
   MTP_CASE(16, 1)
-#endif
   MTP_CASE(32, 1)
-#ifndef MTP_EXP_ONLY_KL32
   MTP_CASE(64, 1)
   MTP_CASE(64, 2)
   MTP_CASE(64, 3)
   MTP_CASE(64, 4)
-#endif
 #undef MTP_CASE
   return hipErrorInvalidValue;
 }
@@ -1712,6 +1647,26 @@ hipError_t mtp_launch_ev_finish(double *ev_slots, double *ev, hipStream_t st)
 {
   hipLaunchKernelGGL(mtp_ev_finish, dim3(7), dim3(512), 0, st, ev_slots, ev);
   return hipGetLastError();
+}
+
+const char *mtp_kernel_build_flags()
+{
+#define MTP_STR2(x) #x
+#define MTP_STR(x) MTP_STR2(x)
+  return ""
+#if MTP_PU != 2
+      "MTP_PU=" MTP_STR(MTP_PU) " "
+#endif
+#if MTP_LD != 1
+      "MTP_LD=" MTP_STR(MTP_LD) " "
+#endif
+#if MTP_POLY_CH != 8
+      "MTP_POLY_CH=" MTP_STR(MTP_POLY_CH) " "
+#endif
+#if MTP_GRADE_TPB != 512 || MTP_GRADE_WPE != 2
+      "MTP_GRADE_TPB=" MTP_STR(MTP_GRADE_TPB) " "
+#endif
+      ;
 }
 
 hipError_t mtp_launch_zero(double *p, size_t n, hipStream_t st)   // p 16-byte aligned (hipMalloc / torch allocations are)

@@ -184,6 +184,12 @@ struct mtp_ghosts {
     }                                                                                       \
   } while (0)
 
+static int ghosts_null_stream(mtp_ghosts *g, const char *fn)
+{
+  g->last_error = std::string(fn) + ": a NULL stream is not accepted (no context to take a stream from)";
+  return MTP_ERR_ARG;
+}
+
 extern "C" {
 
 int mtp_ghosts_create(int device_id, mtp_ghosts **out)
@@ -207,6 +213,7 @@ int mtp_ghosts_build(mtp_ghosts *g, void *stream, double *d_x, int nlocal, int c
                      double rghost, int *nall_out)
 {
   if (!g || !d_x || nlocal < 0 || capacity < nlocal || !box || !(rghost > 0.0) || !nall_out) return MTP_ERR_ARG;
+  if (!stream) return ghosts_null_stream(g, "mtp_ghosts_build");
   for (int a = 0; a < 3; a++)
     if (!(box[a] >= rghost)) {   // one image per direction and sign: the shell must not be thicker than the box
       g->last_error = "mtp_ghosts_build: box edge shorter than the ghost cutoff";
@@ -270,6 +277,7 @@ int mtp_ghosts_build(mtp_ghosts *g, void *stream, double *d_x, int nlocal, int c
 int mtp_ghosts_forward(mtp_ghosts *g, void *stream, double *d_x)
 {
   if (!g || !d_x) return MTP_ERR_ARG;
+  if (!stream) return ghosts_null_stream(g, "mtp_ghosts_forward");
   if (g->nghost > 0)
     hipLaunchKernelGGL(ghosts_forward_kernel, dim3((3 * g->nghost + 255) / 256), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), d_x, g->nlocal, g->d_owner, g->d_shift, 3 * g->nghost);
@@ -280,6 +288,7 @@ int mtp_ghosts_forward(mtp_ghosts *g, void *stream, double *d_x)
 int mtp_ghosts_reverse(mtp_ghosts *g, void *stream, double *d_f)
 {
   if (!g || !d_f) return MTP_ERR_ARG;
+  if (!stream) return ghosts_null_stream(g, "mtp_ghosts_reverse");
   if (g->nghost > 0)
     hipLaunchKernelGGL(ghosts_reverse_kernel, dim3((3 * g->nghost + 255) / 256), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), d_f, g->nlocal, g->d_owner, 3 * g->nghost);
@@ -291,12 +300,14 @@ int mtp_ghosts_reverse_finish(mtp_ghosts *g, mtp_context *ctx, void *stream, int
 {
   if (!g || !ctx || !d_f) return MTP_ERR_ARG;
   // the tally fold of a force call made with finish_tallies = 0 rides in the launch that folds the ghost forces
+  // (a context is at hand: NULL -> the context's stream, as in mtp_compute_device)
   return mtp_internal_finish_unpack(ctx, stream, eflag, vflag, d_ev, d_f, g->d_owner, d_f + 3 * (size_t) g->nlocal, 3 * g->nghost);
 }
 
 int mtp_ghosts_types(mtp_ghosts *g, void *stream, int *d_type)
 {
   if (!g || !d_type) return MTP_ERR_ARG;
+  if (!stream) return ghosts_null_stream(g, "mtp_ghosts_types");
   if (g->nghost > 0)
     hipLaunchKernelGGL(ghosts_types_kernel, dim3((g->nghost + 255) / 256), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), d_type, g->nlocal, g->d_owner, g->nghost);
@@ -307,7 +318,7 @@ int mtp_ghosts_types(mtp_ghosts *g, void *stream, int *d_type)
 int mtp_nve_initial(void *stream, int nlocal, double *d_x, double *d_v, const double *d_f, const int *d_type,
                     const double *d_inv_mass, double dtf, double dt)
 {
-  if (nlocal < 0 || (nlocal > 0 && (!d_x || !d_v || !d_f || !d_type || !d_inv_mass))) return MTP_ERR_ARG;
+  if (!stream || nlocal < 0 || (nlocal > 0 && (!d_x || !d_v || !d_f || !d_type || !d_inv_mass))) return MTP_ERR_ARG;
   if (nlocal > 0)
     hipLaunchKernelGGL(nve_initial_kernel, dim3((3 * nlocal + 255) / 256), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), d_x, d_v, d_f, d_type, d_inv_mass, dtf, dt, 3 * nlocal);
@@ -317,7 +328,7 @@ int mtp_nve_initial(void *stream, int nlocal, double *d_x, double *d_v, const do
 int mtp_nve_final(void *stream, int nlocal, double *d_v, const double *d_f, const int *d_type,
                   const double *d_inv_mass, double dtf)
 {
-  if (nlocal < 0 || (nlocal > 0 && (!d_v || !d_f || !d_type || !d_inv_mass))) return MTP_ERR_ARG;
+  if (!stream || nlocal < 0 || (nlocal > 0 && (!d_v || !d_f || !d_type || !d_inv_mass))) return MTP_ERR_ARG;
   if (nlocal > 0)
     hipLaunchKernelGGL(nve_final_kernel, dim3((3 * nlocal + 255) / 256), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), d_v, d_f, d_type, d_inv_mass, dtf, 3 * nlocal);
@@ -327,7 +338,7 @@ int mtp_nve_final(void *stream, int nlocal, double *d_v, const double *d_f, cons
 int mtp_nve_monitor(void *stream, int nlocal, const double *d_x, const double *d_x_ref, const double *d_v,
                     const int *d_type, const double *d_mass, double *d_out2)
 {
-  if (nlocal < 0 || !d_out2 || (nlocal > 0 && (!d_x || !d_x_ref || !d_v || !d_type || !d_mass))) return MTP_ERR_ARG;
+  if (!stream || nlocal < 0 || !d_out2 || (nlocal > 0 && (!d_x || !d_x_ref || !d_v || !d_type || !d_mass))) return MTP_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (hipMemsetAsync(d_out2, 0, 2 * sizeof(double), st) != hipSuccess) return MTP_ERR_DEVICE;
   if (nlocal > 0)

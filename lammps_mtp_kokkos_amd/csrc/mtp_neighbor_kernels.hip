@@ -164,7 +164,75 @@ __global__ void nb_iota(int *v, int n)
   if (i < n) v[i] = i;
 }
 
+// ---- LAMMPS-KOKKOS list view -> the internal CSR (mtp_set_neighbors_device_2d) -------------------------------------
+// counts[ii] = d_numneigh[d_ilist[ii]] (+ their maximum)
+__global__ void __launch_bounds__(256) nb2d_count(int inum, const int *__restrict__ ilist, const int *__restrict__ numneigh,
+                                                  int cap, int *__restrict__ counts, int *__restrict__ info)
+{
+  const int ii = blockIdx.x * 256 + threadIdx.x;
+  if (ii > inum) return;
+  int c = 0;
+  if (ii < inum) {
+    c = numneigh[ilist[ii]];
+    if (c < 0 || c > cap) {   // a row longer than the view's second extent: refuse (the host reports it)
+      atomicExch(info + 2, 1);
+      c = 0;
+    }
+    atomicMax(info + 1, c);
+  }
+  counts[ii] = c;
+}
+
+// neigh[first[ii] + jj] = d_neighbors(i, jj), i = d_ilist[ii].  One wavefront per ROWS consecutive rows; the element
+// (i, jj) sits at i * stride_i + jj * stride_jj (KOKKOS LayoutLeft on GPUs: stride_i = 1, lanes over jj read with
+// stride extent(0) -- so for that layout lanes run over the rows instead and the wavefront walks jj; LayoutRight:
+// stride_jj = 1, lanes over jj read coalesced).  The special-bond bits stay in the entries (the force kernel masks
+// them with NEIGHMASK like pair_mtp.cpp:114).
+template <bool LANES_OVER_ROWS>
+__global__ void __launch_bounds__(256) nb2d_fill(int inum, const int *__restrict__ ilist, const int *__restrict__ first,
+                                                 const int *__restrict__ nb, long long stride_i, long long stride_jj,
+                                                 int *__restrict__ neigh)
+{
+  if (LANES_OVER_ROWS) {
+    const int ii = blockIdx.x * 256 + threadIdx.x;
+    if (ii >= inum) return;
+    const int beg = first[ii], n = first[ii + 1] - beg;
+    const int *row = nb + (long long) ilist[ii] * stride_i;
+    for (int jj = 0; jj < n; jj++) neigh[beg + jj] = row[(long long) jj * stride_jj];
+  } else {
+    const int lane = threadIdx.x & 63;
+    const int ii = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ii >= inum) return;
+    const int beg = first[ii], n = first[ii + 1] - beg;
+    const int *row = nb + (long long) ilist[ii] * stride_i;
+    for (int jj = lane; jj < n; jj += 64) neigh[beg + jj] = row[(long long) jj * stride_jj];
+  }
+}
+
 }   // namespace
+
+// stage 1 (neigh == nullptr): counts[inum + 1] -> first[inum + 1], d_info = {entries, longest row, bad-row flag};
+// stage 2: fills neigh[]
+hipError_t mtp_launch_list_from_2d(int inum, const int *d_ilist, const int *d_numneigh, const int *d_neighbors,
+                                   long long stride_i, long long stride_jj, int cap, int *counts, void *cub_tmp,
+                                   size_t cub_bytes, int *first, int *neigh, int *d_info, hipStream_t st)
+{
+  hipError_t e;
+  if (!neigh) {
+    if ((e = hipMemsetAsync(d_info, 0, 3 * sizeof(int), st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(nb2d_count, dim3((inum + 1 + 255) / 256), dim3(256), 0, st, inum, d_ilist, d_numneigh, cap, counts, d_info);
+    if ((e = hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, counts, first, inum + 1, st)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(d_info, first + inum, sizeof(int), hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+  } else if (inum > 0) {
+    if (stride_jj == 1)
+      hipLaunchKernelGGL((nb2d_fill<false>), dim3((inum + 3) / 4), dim3(256), 0, st, inum, d_ilist, first, d_neighbors, stride_i,
+                         stride_jj, neigh);
+    else
+      hipLaunchKernelGGL((nb2d_fill<true>), dim3((inum + 255) / 256), dim3(256), 0, st, inum, d_ilist, first, d_neighbors,
+                         stride_i, stride_jj, neigh);
+  }
+  return hipGetLastError();
+}
 
 // Builds the list into caller-provided device buffers in two calls around one host read of the entry count:
 //   stage 1 (neigh == nullptr): bins, counts, row offsets; writes {total entries, max row length} to d_info[2]

@@ -93,6 +93,12 @@ def decompose(pos, box, types, nranks, rank, list_cutoff=7.0, with_lists=True):
     """Build rank `rank`'s shard of a periodic orthogonal system.  Every rank runs this on
     the same global arrays (a static decomposition, valid until atoms migrate -- the
     situation between two LAMMPS re-neighbourings)."""
+    return decompose_all(pos, box, types, nranks, list_cutoff, with_lists, ranks=[rank])[0]
+
+
+def decompose_all(pos, box, types, nranks, list_cutoff=7.0, with_lists=True, ranks=None):
+    """The shards of `ranks` (default: all) of one decomposition; the ghost images of every sub-box are found once and
+    shared by the plans (a rank's receive list is its own images, its send lists are its atoms among the peers')."""
     pos = np.asarray(pos, dtype=np.float64)
     box = np.asarray(box, dtype=np.float64)
     types = np.ones(len(pos), dtype=np.int32) if types is None else np.asarray(types, dtype=np.int32)
@@ -105,34 +111,39 @@ def decompose(pos, box, types, nranks, rank, list_cutoff=7.0, with_lists=True):
         c = np.array([r // (g[1] * g[2]), (r // g[2]) % g[1], r % g[2]])
         return c * box / g, (c + 1) * box / g
 
-    owned = np.nonzero(owner == rank)[0]
-    local_of = -np.ones(len(pos), dtype=np.int64)
-    local_of[owned] = np.arange(len(owned))
-    lo, hi = sub_box(rank)
-    gid, gsh = _ghost_images(pos, box, lo, hi, list_cutoff, owner, rank)
-    recv_counts = [int((owner[gid] == q).sum()) for q in range(nranks)]
-    x_ghost = pos[gid] + gsh * box
-    x0 = np.concatenate([pos[owned], x_ghost])
-    ty = np.concatenate([types[owned], types[gid]])
-    # what every peer needs from me, in the order the peer stores it
-    send_idx, send_shift, send_counts = [], [], []
+    images = []                                               # per rank q: (global ids, integer shifts) of its ghosts
     for q in range(nranks):
         qlo, qhi = sub_box(q)
-        qid, qsh = _ghost_images(pos, box, qlo, qhi, list_cutoff, owner, q)
-        m = owner[qid] == rank
-        send_idx.append(local_of[qid[m]])
-        send_shift.append(qsh[m] * box)
-        send_counts.append(int(m.sum()))
-    nlocal = len(owned)
-    if with_lists:
-        first, neigh = full_neighbor_list(x0, nlocal, list_cutoff)
-    else:
-        first, neigh = np.zeros(nlocal + 1, np.int32), np.zeros(0, np.int32)
-    return HaloPlan(rank=rank, nranks=nranks, grid=grid, nlocal=nlocal, nghost=len(gid), owned_global=owned,
-                    x0=x0, types=ty, ilist=np.arange(nlocal, dtype=np.int32), first=first, neigh=neigh,
-                    send_idx=np.concatenate(send_idx) if send_idx else np.zeros(0, np.int64),
-                    send_shift=np.concatenate(send_shift) if send_shift else np.zeros((0, 3)),
-                    send_counts=send_counts, recv_counts=recv_counts, ghost_global=gid)
+        images.append(_ghost_images(pos, box, qlo, qhi, list_cutoff, owner, q))
+    plans = []
+    for rank in (range(nranks) if ranks is None else ranks):
+        owned = np.nonzero(owner == rank)[0]
+        local_of = -np.ones(len(pos), dtype=np.int64)
+        local_of[owned] = np.arange(len(owned))
+        gid, gsh = images[rank]
+        recv_counts = [int((owner[gid] == q).sum()) for q in range(nranks)]
+        x_ghost = pos[gid] + gsh * box
+        x0 = np.concatenate([pos[owned], x_ghost])
+        ty = np.concatenate([types[owned], types[gid]])
+        # what every peer needs from me, in the order the peer stores it
+        send_idx, send_shift, send_counts = [], [], []
+        for q in range(nranks):
+            qid, qsh = images[q]
+            m = owner[qid] == rank
+            send_idx.append(local_of[qid[m]])
+            send_shift.append(qsh[m] * box)
+            send_counts.append(int(m.sum()))
+        nlocal = len(owned)
+        if with_lists:
+            first, neigh = full_neighbor_list(x0, nlocal, list_cutoff)
+        else:
+            first, neigh = np.zeros(nlocal + 1, np.int32), np.zeros(0, np.int32)
+        plans.append(HaloPlan(rank=rank, nranks=nranks, grid=grid, nlocal=nlocal, nghost=len(gid), owned_global=owned,
+                              x0=x0, types=ty, ilist=np.arange(nlocal, dtype=np.int32), first=first, neigh=neigh,
+                              send_idx=np.concatenate(send_idx) if send_idx else np.zeros(0, np.int64),
+                              send_shift=np.concatenate(send_shift) if send_shift else np.zeros((0, 3)),
+                              send_counts=send_counts, recv_counts=recv_counts, ghost_global=gid))
+    return plans
 
 
 class HaloExchange:

@@ -58,20 +58,27 @@ def make_ghosts(pos, box, rghost, lo=None):
     return np.concatenate(xs), np.concatenate(owners)
 
 
-def full_neighbor_list(x, nlocal, cutoff):
-    """CSR full list over the first nlocal atoms: every j != i with |x_j - x_i| <= cutoff."""
+def full_neighbor_list(x, nlocal, cutoff, chunk=65536):
+    """CSR full list over the first nlocal atoms: every j != i with |x_j - x_i| <= cutoff.  Rows are queried in
+    chunks, so the Python lists of a 500k-atom system never exist all at once."""
     from scipy.spatial import cKDTree
 
     tree = cKDTree(x)
-    lists = tree.query_ball_point(x[:nlocal], cutoff, workers=-1, return_sorted=True)
-    counts = np.fromiter((len(l) - 1 for l in lists), dtype=np.int64, count=nlocal)
+    counts = np.zeros(nlocal, dtype=np.int64)
+    parts = []
+    for c0 in range(0, nlocal, chunk):
+        c1 = min(nlocal, c0 + chunk)
+        lists = tree.query_ball_point(x[c0:c1], cutoff, workers=-1, return_sorted=True)
+        lens = np.fromiter((len(l) for l in lists), dtype=np.int64, count=c1 - c0)
+        flat = np.fromiter((j for l in lists for j in l), dtype=np.int32, count=int(lens.sum()))
+        rows = np.repeat(np.arange(c0, c1, dtype=np.int64), lens)
+        keep = flat != rows                                   # the atom itself
+        parts.append(flat[keep])
+        counts[c0:c1] = lens - 1
     first = np.zeros(nlocal + 1, dtype=np.int64)
     np.cumsum(counts, out=first[1:])
-    neigh = np.empty(first[-1], dtype=np.int32)
-    for i, l in enumerate(lists):
-        a = np.asarray(l, dtype=np.int32)
-        neigh[first[i]:first[i + 1]] = a[a != i]
-    assert first[-1] < 2 ** 31
+    neigh = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int32)
+    assert first[-1] < 2 ** 31 and len(neigh) == first[-1]
     return first.astype(np.int32), neigh
 
 

@@ -105,3 +105,50 @@ def test_overlap_order_partitions_rows_into_interior_boundary_interior():
             has_ghost = bool((row >= plan.nlocal).any())
             if r < na or r >= na + nb:
                 assert not has_ghost          # the overlapped ranges never read a ghost position
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_c_side_halo_tables_equal_the_plan(world):
+    """mtp_halo_layout (host only; the tables mtp_halo_create hands to ncclSend / ncclRecv, csrc/mtp_halo.hip
+    `exchange`) against domain.py's plan: offsets are the running sums of the counts, the two sides of every
+    (source, destination) segment agree on its length, and the atoms a rank sends to a peer are exactly the ghosts the
+    peer expects from it, in the peer's storage order."""
+    from lammps_mtp_kokkos_amd import capi
+    from lammps_mtp_kokkos_amd.domain import decompose_all
+    pos, box = mtpgen.bcc_lattice(10, 10, 10)
+    types = (np.random.default_rng(5).random(len(pos)) < 0.2).astype(np.int32) + 1
+    plans = decompose_all(pos, box, types, world, 7.0, with_lists=False)
+    lay = [capi.halo_layout(p) for p in plans]
+    for p, (so, ro) in zip(plans, lay):
+        assert list(so) == [0] + list(np.cumsum(p.send_counts)) and list(ro) == [0] + list(np.cumsum(p.recv_counts))
+        assert so[-1] == len(p.send_idx) and ro[-1] == p.nghost
+    for r, pr in enumerate(plans):
+        for q, pq in enumerate(plans):
+            assert pr.recv_counts[q] == pq.send_counts[r]
+            sent = pq.owned_global[pq.send_idx[lay[q][0][r]: lay[q][0][r + 1]]]          # what q packs for r
+            expected = pr.ghost_global[lay[r][1][q]: lay[r][1][q + 1]]                   # r's ghosts owned by q
+            assert np.array_equal(sent, expected)
+            shifted = pq.x0[pq.send_idx[lay[q][0][r]: lay[q][0][r + 1]]] + pq.send_shift[lay[q][0][r]: lay[q][0][r + 1]]
+            assert np.array_equal(shifted, pr.x0[pr.nlocal + lay[r][1][q]: pr.nlocal + lay[r][1][q + 1]])
+
+
+def test_c_side_halo_layout_rejects_bad_plans():
+    from lammps_mtp_kokkos_amd import capi
+    from lammps_mtp_kokkos_amd.domain import decompose
+    pos, box = mtpgen.bcc_lattice(8, 8, 8)
+    p = decompose(pos, box, None, 2, 0, 7.0, with_lists=False)
+    p.recv_counts = [p.recv_counts[0] + 1, p.recv_counts[1]]
+    with pytest.raises(capi.MtpError) as e:
+        capi.halo_layout(p)
+    assert e.value.code == -20 and "add up" in str(e.value)
+    p = decompose(pos, box, None, 2, 0, 7.0, with_lists=False)
+    p.send_idx = p.send_idx.copy()
+    p.send_idx[0] = p.nlocal
+    with pytest.raises(capi.MtpError) as e:
+        capi.halo_layout(p)
+    assert "outside the owned atoms" in str(e.value)
+
+
+def test_shipped_library_carries_no_experiment_switches():
+    from lammps_mtp_kokkos_amd import capi
+    assert capi.build_flags() == ""

@@ -525,3 +525,113 @@ def test_deterministic_mode_is_bitwise_reproducible():
     _close(runs[0]["f"], want["f"], "deterministic forces")
     ctx.set_deterministic(False)
     _close(ctx.compute(s.x, s.types)["f"], runs[0]["f"], "atomic vs fixed-point forces", atol=1e-10)
+
+
+# ---- LAMMPS-KOKKOS list views (mtp_set_neighbors_device_2d) and the NULL-stream rule -------------------------------
+
+@pytest.mark.parametrize("layout", ["left", "right"])
+def test_kokkos_2d_neighbour_view_both_layouts(layout):
+    """The list as the reference's /kk styles read it on the device -- d_ilist(ii), d_numneigh(i), padded 2-D view
+    d_neighbors(i, jj) (/root/reference/LAMMPS/KOKKOS/pair_mtp_kokkos.cpp:236-239, pair_mtp_kokkos.h:115) -- in both
+    Kokkos layouts, with a permuted subset ilist, ragged / empty rows, special-bond bits in the entries and garbage in
+    the padding; compacted on the device, then forces / energies / virials against the oracle on the same list."""
+    import torch
+    s = _system((4, 4, 4))
+    rng = np.random.default_rng(31)
+    keep = rng.permutation(s.nlocal)[: s.nlocal - 9].astype(np.int32)
+    numneigh = np.zeros(s.nall, np.int32)                         # indexed by atom id, as in LAMMPS
+    maxn = int(np.diff(s.first).max()) + 5                        # extent(1) of the view: longer than any row
+    view = rng.integers(0, s.nall, size=(s.nall, maxn)).astype(np.int32)      # padding = garbage
+    rows = {}
+    for ii, i in enumerate(keep):
+        r = s.neigh[s.first[i]:s.first[i + 1]].copy()
+        rng.shuffle(r)
+        if ii % 7 == 0:
+            r = r[: len(r) // 2]
+        if ii % 13 == 0:
+            r = r[:0]
+        r = (r.astype(np.uint32) | np.uint32(int(rng.integers(0, 4)) << 30)).view(np.int32)   # LAMMPS special bits
+        rows[int(i)] = r
+        numneigh[i] = len(r)
+        view[i, : len(r)] = r
+    dev = torch.device("cuda:0")
+    stream = capi.use_private_torch_stream(dev)
+    if layout == "left":                                          # Kokkos::LayoutLeft: (i, jj) at i + jj * extent(0)
+        flat = torch.from_numpy(np.ascontiguousarray(view.T).ravel()).to(dev)
+        stride_i, stride_jj = 1, s.nall
+    else:                                                         # LayoutRight: (i, jj) at i * extent(1) + jj
+        flat = torch.from_numpy(view.ravel().copy()).to(dev)
+        stride_i, stride_jj = maxn, 1
+    path = os.path.join(POT, "W_L16.mtp")
+    ctx = capi.Context(capi.Potential(path), 0)
+    il = torch.from_numpy(keep).to(dev)
+    nn = torch.from_numpy(numneigh).to(dev)
+    ctx.set_neighbors_device_2d(il, nn, flat, stride_i, stride_jj, maxn, s.nall, stream=stream.cuda_stream)
+    first = np.zeros(len(keep) + 1, np.int32)
+    first[1:] = np.cumsum([len(rows[int(i)]) for i in keep])
+    neigh = np.concatenate([rows[int(i)] for i in keep]).astype(np.int32)
+    got_first, got_neigh = ctx.neighbors_to_host()
+    assert np.array_equal(got_first, first) and np.array_equal(got_neigh, neigh)         # integer work: bit-exact
+    x = torch.from_numpy(s.x).to(dev)
+    ty = torch.from_numpy(s.types).to(dev)
+    f = torch.zeros((s.nall, 3), dtype=torch.float64, device=dev)
+    ea = torch.zeros(s.nall, dtype=torch.float64, device=dev)
+    ev = torch.zeros(8, dtype=torch.float64, device=dev)
+    ctx.compute_device(x, ty, f, eflag=3, vflag=1, eatom_t=ea, ev_t=ev, stream=stream.cuda_stream)
+    ctx.synchronize(stream.cuda_stream)
+    want = _oracle(path).compute(s.x, s.types, keep, first, neigh, eflag=3, vflag=1)
+    _close(f.cpu().numpy(), want["f"], "forces from the 2-D view")
+    _close(ea.cpu().numpy(), want["eatom"], "eatom", atol=1e-10)
+    evh = ev.cpu().numpy()
+    assert abs(evh[0] - want["energy"]) <= 1e-10 * len(keep) * max(1.0, abs(want["energy"]) / len(keep))
+    _close(evh[1:7], want["virial"], "virial", atol=1e-8)
+    # a row longer than the view's second extent is refused, not read
+    numneigh[keep[3]] = maxn + 1
+    with pytest.raises(capi.MtpError) as e:
+        ctx.set_neighbors_device_2d(il, torch.from_numpy(numneigh).to(dev), flat, stride_i, stride_jj, maxn, s.nall,
+                                    stream=stream.cuda_stream)
+    assert e.value.code == -20
+
+
+def test_null_stream_rule():
+    """include/mtp_mi355x.h "Streams": entry points with a context map NULL to the context's stream; those without one
+    (halo, ghosts, nve, zero) reject NULL instead of falling onto the legacy null stream."""
+    import ctypes as C
+    import torch
+    from lammps_mtp_kokkos_amd.domain import decompose
+    L = capi.lib()
+    dev = torch.device("cuda:0")
+    t = torch.zeros(64, dtype=torch.float64, device=dev)
+    assert L.mtp_zero_async(None, C.c_void_p(t.data_ptr()), C.c_longlong(64)) == -20
+    pos, box = mtpgen.bcc_lattice(8, 8, 8)
+    plan = decompose(pos, box, None, 1, 0, 7.0, with_lists=False)
+    halo = capi.Halo(plan, 0, None)
+    x = torch.from_numpy(plan.x0).to(dev)
+    for call in (halo.forward_begin, halo.forward, halo.reverse, lambda a, st: halo.pack_forward(a, st),
+                 lambda a, st: halo.unpack_reverse(a, st)):
+        with pytest.raises(capi.MtpError) as e:
+            call(x, None)
+        assert e.value.code == -20 and "NULL stream" in str(e.value)
+    g = capi.Ghosts(0)
+    with pytest.raises(capi.MtpError) as e:
+        g.build(x, plan.nlocal, box, 7.0, stream=None)
+    assert e.value.code == -20
+    iv = torch.zeros(1, dtype=torch.float64, device=dev)
+    ty = torch.ones(plan.nall, dtype=torch.int32, device=dev)
+    with pytest.raises(capi.MtpError):
+        capi.nve_final(plan.nlocal, x, x, ty, iv, 0.0, stream=None)
+    # with a context NULL is the context's stream: a whole call runs and synchronises on it
+    s = _system((3, 3, 3))
+    path = os.path.join(POT, "W_L8.mtp")
+    ctx = capi.Context(capi.Potential(path), 0)
+    il, fi, ne = (torch.from_numpy(a).to(dev) for a in (s.ilist, s.first, s.neigh))
+    torch.cuda.synchronize()
+    ctx.set_neighbors_device(il, fi, ne, s.nall, int(np.diff(s.first).max()))
+    xs = torch.from_numpy(s.x).to(dev)
+    tys = torch.from_numpy(s.types).to(dev)
+    f = torch.zeros((s.nall, 3), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    ctx.compute_device(xs, tys, f, stream=None)
+    ctx.synchronize(None)
+    want = _oracle(path).compute(s.x, s.types, s.ilist, s.first, s.neigh)
+    _close(f.cpu().numpy(), want["f"], "forces on the context's own stream")
