@@ -274,3 +274,140 @@ def test_threaded_oracle_matches_serial_oracle(tmp_path, level, species, threads
     assert abs(a["energy"] - b["energy"]) <= 1e-11 * max(1.0, abs(a["energy"]))
     assert np.abs(a["virial"] - b["virial"]).max() <= 1e-10 * max(1.0, np.abs(a["virial"]).max())
     assert np.abs(a["vatom"] - b["vatom"]).max() <= 1e-12 * max(1.0, np.abs(a["vatom"]).max())
+
+
+# ---- the same independent checks on the COMMITTED tables the BASELINE configs run on ---------------------------------
+# (potentials/WRe_L20.mtp: config 4; W_L16.mtp: configs 2, 3; W_L16_nbh.almtp: config 5).  The oracle is unpinned with
+# respect to a running reference, so these -- definition, finite differences, strain derivative -- are what stands
+# under it at exactly the table shapes that are benchmarked.
+
+import os
+
+import _mtpfile
+
+_POT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "potentials")
+
+
+def test_committed_level20_two_species_table_matches_einsum_definition():
+    """site energies of 16 atoms (2 x 2 x 2 cells, W + Re at random) with potentials/WRe_L20.mtp: oracle
+    (pair_mtp.cpp:154-212 restated) against full Cartesian tensors contracted graph by graph -- 460 scalars of up to
+    ten tensors, ranks up to 8."""
+    path = os.path.join(_POT, "WRe_L20.mtp")
+    pot = _mtpfile.read_committed(path, 20)
+    assert (pot.species_count, len(pot.table.graphs), pot.table.radial_funcs) == (2, 460, 5)
+    s = _system(ncell=(2, 2, 2), species=2)
+    assert s.nlocal == 16 and set(s.types[:16]) == {1, 2}
+    res = Oracle(path).compute(s.x, s.types, s.ilist, s.first, s.neigh)
+    E, _ = defn.site_energies(pot, pot.table.graphs, s)
+    np.testing.assert_allclose(res["eatom"][: s.nlocal], E, rtol=5e-11, atol=1e-11)
+    assert abs(res["energy"] - E.sum()) < 1e-10 * max(1.0, abs(E.sum()))
+
+
+def _fd_setup(fname, ncell=(3, 3, 3), species=1):
+    path = os.path.join(_POT, fname)
+    pos, box = mtpgen.bcc_lattice(*ncell)
+    types = np.random.default_rng(5).integers(1, species + 1, size=len(pos)).astype(np.int32)
+    return path, pos, box, types
+
+
+def test_committed_level16_forces_are_central_differences_of_the_energy():
+    """F = -dE/dx (pair_mtp.cpp:196-254: products, reverse mode, scatter onto i and j) at level 16 on W_L16.mtp"""
+    path, pos, box, types = _fd_setup("W_L16.mtp")
+    o = Oracle(path)
+
+    def energy(p):
+        s = periodic_system(p, box, types, 7.0)
+        return o.compute(s.x, s.types, s.ilist, s.first, s.neigh), s
+
+    r, s = energy(pos)
+    F = s.fold_forces(r["f"])
+    assert np.abs(F.sum(0)).max() < 1e-10 * max(1.0, np.abs(F).max())
+    assert abs(r["energy"] - r["eatom"][: s.nlocal].sum()) < 1e-10 * max(1.0, abs(r["energy"]))
+    h = 1e-5
+    for (a, c) in [(0, 0), (11, 1), (29, 2), (53, 0), (40, 1)]:
+        pp = pos.copy(); pp[a, c] += h
+        pm = pos.copy(); pm[a, c] -= h
+        fd = -(energy(pp)[0]["energy"] - energy(pm)[0]["energy"]) / (2 * h)
+        assert abs(fd - F[a, c]) < 2e-7 * max(1.0, np.abs(F).max()), (a, c, fd, F[a, c])
+
+
+def test_committed_level20_two_species_forces_are_central_differences():
+    path, pos, box, types = _fd_setup("WRe_L20.mtp", species=2)
+    o = Oracle(path)
+
+    def energy(p):
+        s = periodic_system(p, box, types, 7.0)
+        return o.compute(s.x, s.types, s.ilist, s.first, s.neigh), s
+
+    r, s = energy(pos)
+    F = s.fold_forces(r["f"])
+    assert np.abs(F.sum(0)).max() < 1e-10 * max(1.0, np.abs(F).max())
+    h = 1e-5
+    for (a, c) in [(3, 0), (17, 2), (44, 1)]:
+        pp = pos.copy(); pp[a, c] += h
+        pm = pos.copy(); pm[a, c] -= h
+        fd = -(energy(pp)[0]["energy"] - energy(pm)[0]["energy"]) / (2 * h)
+        assert abs(fd - F[a, c]) < 2e-7 * max(1.0, np.abs(F).max()), (a, c, fd, F[a, c])
+
+
+def test_committed_level16_virial_is_the_strain_derivative():
+    """isotropic AND shear strain: dE/d(eps_ab) = -virial_ab (LAMMPS sign, virial_ab = sum r_a f_b; pair_mtp.cpp:257-277
+    symmetrises the off-diagonals), and sum_i vatom_i = virial"""
+    path, pos, box, types = _fd_setup("W_L16.mtp")
+    o = Oracle(path)
+    s0 = periodic_system(pos, box, types, 7.0)
+    r0 = o.compute(s0.x, s0.types, s0.ilist, s0.first, s0.neigh)
+
+    def energy_strained(eps):
+        # the ghost images are images of the UNSTRAINED cell mapped through the same strain (a sheared box is not
+        # orthogonal, so the images are strained rather than regenerated); the list is index-based
+        x = s0.x @ (np.eye(3) + eps).T
+        return o.compute(x, s0.types, s0.ilist, s0.first, s0.neigh)["energy"]
+
+    h = 1e-6
+    comps = [((0, 0), 0), ((1, 1), 1), ((2, 2), 2), ((0, 1), 3), ((0, 2), 4), ((1, 2), 5)]
+    for (a, b), v in comps:
+        e = np.zeros((3, 3))
+        e[a, b] = e[b, a] = h if a != b else h
+        # symmetric strain: for a != b both eps_ab and eps_ba are switched on, dE = -(v_ab + v_ba) h = -2 v_ab h
+        dE = (energy_strained(e) - energy_strained(-e)) / (2 * h)
+        want = -r0["virial"][v] * (2.0 if a != b else 1.0)
+        assert abs(dE - want) < 2e-6 * max(1.0, abs(want)), ((a, b), dE, want)
+    np.testing.assert_allclose(r0["vatom"][: s0.nlocal].sum(0), r0["virial"], rtol=1e-12, atol=1e-11)
+
+
+def test_committed_level16_nbh_candidate_vector_by_finite_differences(tmp_path):
+    """config 5's file: c = dE_i/dtheta (pair_mtp_extrapolation.cpp:193-198, 235-252, 323-329).  Linear block = the
+    basis values from the definition; species block = indicator; radial block = central differences of the site energy
+    with respect to single radial coefficients (rewritten files); grade = max |A^-1 c| with the file's own inverse."""
+    path = os.path.join(_POT, "W_L16_nbh.almtp")
+    pot = _mtpfile.read_committed(path, 16)
+    assert pot.mvs_mode == "nbh" and pot.inverse_active_set.shape == (149, 149)
+    s = _system(ncell=(2, 2, 2))
+    o = Oracle(path, selection=True)
+    ext = o.compute(s.x, s.types, s.ilist, s.first, s.neigh, extrapolation=True)
+    plain = Oracle(os.path.join(_POT, "W_L16.mtp")).compute(s.x, s.types, s.ilist, s.first, s.neigh)
+    np.testing.assert_array_equal(ext["f"], plain["f"])          # the same coefficients: W_L16.mtp + the selection state
+    _, Bv = defn.site_energies(pot, pot.table.graphs, s)
+    Mu = pot.table.radial_funcs
+    nrad = Mu * 8
+    assert nrad + 1 + Bv.shape[1] == 149
+    for i in [0, 7, 12]:
+        row = (s.ilist[i:i + 1], np.array([0, s.first[i + 1] - s.first[i]], dtype=np.int32), s.neigh[s.first[i]:s.first[i + 1]])
+        c = o.compute(s.x, s.types, *row, extrapolation=True)["coeff_ders"]
+        np.testing.assert_allclose(c[nrad + 1:], Bv[i], rtol=1e-10, atol=1e-11)
+        assert c[nrad] == 1.0
+        assert abs(np.abs(pot.inverse_active_set @ c).max() - ext["grades"][i]) < 1e-12 * max(1.0, ext["grades"][i])
+        for flat in [0, 5, 8 + 3, 2 * 8 + 7, 3 * 8 + 1, nrad - 1]:          # every radial function mu is touched
+            h = 1e-6
+            es = []
+            for sign in (+1, -1):
+                p2 = mtpgen.Potential(pot.table, 1, pot.min_dist, pot.max_dist, 8, pot.scaling, pot.radial_coeffs.copy(),
+                                      pot.species_coeffs, pot.moment_coeffs)
+                p2.radial_coeffs.reshape(-1)[flat] += sign * h
+                pth = str(tmp_path / "pert.mtp")
+                mtpgen.write_mtp(p2, pth)
+                es.append(Oracle(pth).compute(s.x, s.types, *row)["eatom"][s.ilist[i]])
+            fd = (es[0] - es[1]) / (2 * h)
+            assert abs(fd - c[flat]) < 1e-6 * max(1.0, abs(c[flat])), (i, flat, fd, c[flat])
+    assert ext["max_grade"] == ext["grades"][: s.nlocal].max()
