@@ -22,6 +22,7 @@
 #ifndef MTP_MI355X_H
 #define MTP_MI355X_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -173,6 +174,32 @@ int mtp_compute_device_rows(mtp_context *ctx, void *stream, int row_begin, int r
                             double *d_f, double *d_eatom, double *d_vatom, double *d_ev, double *d_grades,
                             double *d_max_grade, double *d_coeff_ders);
 int mtp_synchronize(mtp_context *ctx, void *stream);
+
+/* ---- device-resident step: what the reference's /kk styles do around their kernels --------------------------------
+ * PairMTPKokkos::compute (KOKKOS/pair_mtp_kokkos.cpp:197-399) and PairMTPExtrapolationKokkos::compute
+ * (KOKKOS/pair_mtp_extrapolation_kokkos.cpp:274-610) read x / type and write f through LAMMPS-KOKKOS device views
+ * (:231-240) and keep every other output -- eng_vdwl / virial (`ev`), d_eatom, d_vatom, the grades -- in device views
+ * that are copied to the host only when something asks (k_eatom / k_vatom sync :379-388; grades :223-243).  Here those
+ * views belong to the context:
+ *   mtp_compute_resident   zeroes the totals and the requested per-atom arrays on `stream`, then runs the force call of
+ *                          mtp_compute_device (same flags, same accumulate / assign semantics) into them; nothing
+ *                          crosses PCIe and nothing waits;
+ *   mtp_resident_totals    the ONE wait of a step: ev7 = {energy, virial xx,yy,zz,xy,xz,yz} of that call, this rank's
+ *                          maximum grade (neighbourhood mode) and, in configuration mode, sum_i dE_i/dtheta (C doubles,
+ *                          may be NULL); reports the atom-type error like mtp_synchronize;
+ *   mtp_resident_peratom_device / _host   the per-atom arrays of that call -- eatom [nall], vatom [nall][6], grades
+ *                          [nall] -- as a device pointer (valid until the next call that grows them) or copied to the
+ *                          host on request (what `fix pair` / `dump` trigger through extract_peratom,
+ *                          pair_mtp_extrapolation.cpp:641-652). */
+enum { MTP_PERATOM_EATOM = 0, MTP_PERATOM_VATOM = 1, MTP_PERATOM_GRADES = 2 };
+int mtp_compute_resident(mtp_context *ctx, void *stream, const double *d_x, const int *d_type, double *d_f, int eflag,
+                         int vflag, int grade_flag);
+int mtp_resident_totals(mtp_context *ctx, void *stream, double *ev7, double *max_grade, double *coeff_ders);
+int mtp_resident_peratom_device(mtp_context *ctx, int what, const double **d_ptr, int *ncol);
+int mtp_resident_peratom_host(mtp_context *ctx, void *stream, int what, double *host);
+/* `bytes` from a device array to the host, ordered on `stream` and waited for (atomKK->sync(Host, ...) for the few
+ * rows a .cfg record needs, pair_mtp_extrapolation.cpp:401-479, when positions live on the device) */
+int mtp_copy_to_host(mtp_context *ctx, void *stream, void *host, const void *d_src, size_t bytes);
 
 /* PairMTPExtrapolation::calculate_extrapolation_grade (pair_mtp_extrapolation.cpp:347-358)
  * for configuration mode: max_i |sum_j coeff_ders[j] A^-1[i][j]| on the host (C^2 flops,

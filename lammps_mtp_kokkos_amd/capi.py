@@ -29,7 +29,8 @@ EXPORTS = [
     "mtp_halo_forward_begin", "mtp_halo_forward_end", "mtp_halo_forward", "mtp_halo_reverse_begin",
     "mtp_halo_reverse_end", "mtp_halo_reverse", "mtp_halo_allreduce", "mtp_halo_force_step", "mtp_halo_set_overlap",
     "mtp_halo_get_overlap", "mtp_halo_layout", "mtp_halo_pack_forward", "mtp_halo_unpack_reverse", "mtp_halo_get_layout",
-    "mtp_halo_local_exchange", "mtp_set_neighbors_device_2d", "mtp_build_flags",
+    "mtp_halo_local_exchange", "mtp_set_neighbors_device_2d", "mtp_build_flags", "mtp_compute_resident",
+    "mtp_resident_totals", "mtp_resident_peratom_device", "mtp_resident_peratom_host", "mtp_copy_to_host",
     "mtp_ghosts_create", "mtp_ghosts_destroy", "mtp_ghosts_last_error", "mtp_ghosts_build", "mtp_ghosts_forward",
     "mtp_ghosts_reverse", "mtp_ghosts_reverse_finish", "mtp_ghosts_types", "mtp_nve_initial", "mtp_nve_final", "mtp_nve_monitor",
     "mtp_context_set_deterministic", "mtp_zero_async",

@@ -108,6 +108,10 @@ struct mtp_context {
              // grade instantiation (its image also holds the leaf moments' values)
   DevBuf<double> d_cvec, d_ainv_pad, d_ainv_tiled, d_dbasic;
   int cpad = 0, dpad = 0;
+  // device-resident outputs of mtp_compute_resident (the /kk styles' DualViews): which of them the last call filled
+  bool res_valid = false;
+  int res_eflag = 0, res_vflag = 0, res_grade = 0;
+  DevBuf<double> d_res_tot;   // [8 + 1 + C]: ev[8] | max grade | coeff_ders[C], zeroed by one launch per step
   // timing
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -841,6 +845,153 @@ int mtp_set_neighbors_device_2d(mtp_context *c, void *stream, int inum, const in
     c->last_error = std::string(f.what) + ": " + hipGetErrorString(f.e);
     return MTP_ERR_DEVICE;
   }
+}
+
+// ---- device-resident step (include/mtp_mi355x.h, "device-resident step") ------------------------------------------
+int mtp_compute_resident(mtp_context *c, void *stream, const double *d_x, const int *d_type, double *d_f, int eflag, int vflag,
+                         int grade_flag)
+{
+  if (!c || !d_x || !d_type || !d_f) return MTP_ERR_ARG;
+  if (!c->have_list) {
+    c->last_error = "mtp_compute before mtp_set_neighbors";
+    return MTP_ERR_STATE;
+  }
+  if (hipSetDevice(c->device) != hipSuccess) {
+    c->last_error = "hipSetDevice failed";
+    return MTP_ERR_DEVICE;
+  }
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+  const size_t nall = (size_t) c->nall, C = (size_t) c->pot->coeff_count;
+  const bool want_ea = (eflag & MTP_ENERGY_ATOM) != 0, want_va = (vflag & MTP_VIRIAL_ATOM) != 0;
+  const bool cfg = c->pot->configuration_mode != 0;
+  c->res_valid = false;
+  try {
+    // totals: one allocation, padded to an even count, zeroed by ONE launch on the caller's stream
+    const size_t ntot = (8 + 1 + C + 1) / 2 * 2;
+    c->d_res_tot.reserve(ntot);
+    HIP_CHECK(mtp_launch_zero(c->d_res_tot.ptr, ntot, st));
+    if (want_ea) {   // eatom[i] is assigned for i in ilist; every other row reads 0 (LAMMPS zeroes eatom in ev_setup)
+      c->d_eatom.reserve(nall + (nall & 1));
+      HIP_CHECK(mtp_launch_zero(c->d_eatom.ptr, nall + (nall & 1), st));
+    }
+    if (want_va) {
+      c->d_vatom.reserve(6 * nall);
+      HIP_CHECK(mtp_launch_zero(c->d_vatom.ptr, 6 * nall, st));
+    }
+    if (grade_flag && !cfg) {   // grown, never shrunk; rows outside ilist keep their last value (pair_mtp_extrapolation.cpp:91-94)
+      if (c->d_grades.cap < nall) {
+        c->d_grades.reserve(nall + (nall & 1));
+        HIP_CHECK(mtp_launch_zero(c->d_grades.ptr, nall + (nall & 1), st));
+      }
+    }
+  } catch (const HipFail &f) {
+    c->last_error = std::string(f.what) + ": " + hipGetErrorString(f.e);
+    return MTP_ERR_DEVICE;
+  }
+  double *tot = c->d_res_tot.ptr;
+  const int rc = mtp_compute_device(c, reinterpret_cast<void *>(st), d_x, d_type, eflag, vflag, grade_flag, d_f,
+                                    want_ea ? c->d_eatom.ptr : nullptr, want_va ? c->d_vatom.ptr : nullptr, tot,
+                                    grade_flag && !cfg ? c->d_grades.ptr : nullptr, grade_flag ? tot + 8 : nullptr,
+                                    grade_flag && cfg ? tot + 9 : nullptr);
+  if (rc != MTP_OK) return rc;
+  c->res_valid = true;
+  c->res_eflag = eflag;
+  c->res_vflag = vflag;
+  c->res_grade = grade_flag ? 1 : 0;
+  return MTP_OK;
+}
+
+int mtp_resident_totals(mtp_context *c, void *stream, double *ev7, double *max_grade, double *coeff_ders)
+{
+  if (!c) return MTP_ERR_ARG;
+  if (!c->res_valid) {
+    c->last_error = "mtp_resident_totals before mtp_compute_resident";
+    return MTP_ERR_STATE;
+  }
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+  const size_t C = (size_t) c->pot->coeff_count, n = 9 + (coeff_ders && c->res_grade ? C : 0);
+  c->h_tmp.resize(std::max<size_t>(c->h_tmp.size(), 9 + C));
+  if (hipSetDevice(c->device) != hipSuccess ||
+      hipMemcpyAsync(c->h_tmp.data(), c->d_res_tot.ptr, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) {
+    c->last_error = "resident totals: copy failed";
+    return MTP_ERR_DEVICE;
+  }
+  const int rc = mtp_synchronize(c, reinterpret_cast<void *>(st));   // the one wait of the step; reports the atom-type error
+  if (rc != MTP_OK) return rc;
+  if (ev7)
+    for (int q = 0; q < 7; q++) ev7[q] = c->h_tmp[q];
+  if (max_grade) *max_grade = c->res_grade ? c->h_tmp[8] : 0.0;
+  if (coeff_ders && c->res_grade)
+    for (size_t q = 0; q < C; q++) coeff_ders[q] = c->h_tmp[9 + q];
+  return MTP_OK;
+}
+
+static int resident_array(mtp_context *c, int what, const double **ptr, int *ncol)
+{
+  if (!c->res_valid) {
+    c->last_error = "per-atom outputs asked for before mtp_compute_resident";
+    return MTP_ERR_STATE;
+  }
+  switch (what) {
+    case MTP_PERATOM_EATOM:
+      if (!(c->res_eflag & MTP_ENERGY_ATOM)) break;
+      *ptr = c->d_eatom.ptr;
+      *ncol = 1;
+      return MTP_OK;
+    case MTP_PERATOM_VATOM:
+      if (!(c->res_vflag & MTP_VIRIAL_ATOM)) break;
+      *ptr = c->d_vatom.ptr;
+      *ncol = 6;
+      return MTP_OK;
+    case MTP_PERATOM_GRADES:
+      if (!c->d_grades.ptr || c->pot->configuration_mode) break;
+      *ptr = c->d_grades.ptr;
+      *ncol = 1;
+      return MTP_OK;
+    default:
+      return MTP_ERR_ARG;
+  }
+  c->last_error = "this per-atom output was not produced by the last mtp_compute_resident call";
+  return MTP_ERR_STATE;
+}
+
+int mtp_resident_peratom_device(mtp_context *c, int what, const double **d_ptr, int *ncol)
+{
+  if (!c || !d_ptr) return MTP_ERR_ARG;
+  int nc = 0;
+  const int rc = resident_array(c, what, d_ptr, &nc);
+  if (rc == MTP_OK && ncol) *ncol = nc;
+  return rc;
+}
+
+int mtp_resident_peratom_host(mtp_context *c, void *stream, int what, double *host)
+{
+  if (!c || !host) return MTP_ERR_ARG;
+  const double *src = nullptr;
+  int nc = 0;
+  const int rc = resident_array(c, what, &src, &nc);
+  if (rc != MTP_OK) return rc;
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+  if (hipSetDevice(c->device) != hipSuccess ||
+      hipMemcpyAsync(host, src, (size_t) c->nall * nc * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    c->last_error = "resident per-atom output: copy failed";
+    return MTP_ERR_DEVICE;
+  }
+  return MTP_OK;
+}
+
+int mtp_copy_to_host(mtp_context *c, void *stream, void *host, const void *d_src, size_t bytes)
+{
+  if (!c || (bytes > 0 && (!host || !d_src))) return MTP_ERR_ARG;
+  if (bytes == 0) return MTP_OK;
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+  if (hipSetDevice(c->device) != hipSuccess || hipMemcpyAsync(host, d_src, bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    c->last_error = "mtp_copy_to_host failed";
+    return MTP_ERR_DEVICE;
+  }
+  return MTP_OK;
 }
 
 const char *mtp_build_flags(void)

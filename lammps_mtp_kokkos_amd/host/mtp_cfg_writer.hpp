@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 namespace mtp_mi355x {
 
@@ -58,6 +59,11 @@ inline void cfg_write_record(std::FILE *fp, const CfgComm &comm, long natoms, co
     if (comm.send_to_root) comm.send_to_root(mine.data(), mine.size(), comm.ctx);   // :461-462
     return;
   }
+  // rank 0 always receives what the other ranks sent, even without a file to write to (a closed or failed file must
+  // not leave their MPI_Send unmatched)
+  std::vector<std::string> theirs(comm.nprocs > 1 ? (size_t) comm.nprocs - 1 : 0);
+  if (comm.recv_on_root)
+    for (int src = 1; src < comm.nprocs; src++) comm.recv_on_root(src, theirs[(size_t) src - 1], comm.ctx);   // :464-472
   if (!fp) return;
   std::fprintf(fp, "BEGIN_CFG\n");   // :444-459
   std::fprintf(fp, "Size\n");
@@ -71,12 +77,7 @@ inline void cfg_write_record(std::FILE *fp, const CfgComm &comm, long natoms, co
   else
     std::fprintf(fp, "AtomData:  id type       cartes_x      cartes_y      cartes_z\n");
   std::fwrite(mine.data(), 1, mine.size(), fp);
-  if (comm.recv_on_root)
-    for (int src = 1; src < comm.nprocs; src++) {   // :464-472: rank order, so ids ascend through the file
-      std::string theirs;
-      comm.recv_on_root(src, theirs, comm.ctx);
-      std::fwrite(theirs.data(), 1, theirs.size(), fp);
-    }
+  for (const std::string &t : theirs) std::fwrite(t.data(), 1, t.size(), fp);   // rank order, so ids ascend through the file
   std::fprintf(fp, "Feature   MV_grade\t%.6f\n", max_grade);   // :474-477
   std::fprintf(fp, "END_CFG\n\n");
   std::fflush(fp);

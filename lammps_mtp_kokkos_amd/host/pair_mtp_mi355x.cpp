@@ -110,6 +110,41 @@ void PairMTP::set_neighbor_list(const NeighListView &l)
   list_set_ = true;
 }
 
+void PairMTP::bind_device(const DeviceAtomView &a)
+{
+  datom = a;
+  resident_ = true;
+  atom.nlocal = a.nlocal;   // sizes of eatom / vatom / grades and the .cfg writer's atom count
+  atom.nall = a.nall;
+  atom.natoms = a.natoms;
+}
+
+void PairMTP::set_neighbor_list_device(const DeviceNeighListView &l)
+{
+  if (!ctx_) throw Error(MTP_ERR_STATE, "init_style() must run before the neighbour list is handed over");
+  if (!resident_) throw Error(MTP_ERR_STATE, "bind_device() must precede set_neighbor_list_device()");
+  require(mtp_set_neighbors_device_2d(ctx_, datom.stream, l.inum, l.d_ilist, l.d_numneigh, l.d_neighbors, l.stride_i,
+                                      l.stride_jj, l.maxneighs, datom.nall),
+          "mtp_set_neighbors_device_2d");
+  list_set_ = true;
+}
+
+// One device-resident step (KOKKOS/pair_mtp_kokkos.cpp:197-399): everything on datom.stream, one wait for the
+// totals.  The global virial is tallied on the RAW vflag, as PairMTP::compute does (pair_mtp.cpp:257 `if (vflag)`;
+// the reference's /kk styles set no_virial_fdotr_compute and read ev.v the same way, pair_mtp_kokkos.cpp:210, 367-375).
+void PairMTP::compute_resident(int eflag, int vflag, int grade, double *max_grade, double *coeff_ders)
+{
+  require(mtp_compute_resident(ctx_, datom.stream, datom.d_x, datom.d_type, datom.d_f, eflag, vflag, grade), "mtp_compute_resident");
+  double ev[7];
+  require(mtp_resident_totals(ctx_, datom.stream, ev, max_grade, coeff_ders), "mtp_resident_totals");
+  if (eflag_global) eng_vdwl += ev[0];
+  if (vflag)
+    for (int q = 0; q < 6; q++) virial[q] += ev[1 + q];
+  // per-atom tallies reach the host only when the step asked for them (k_eatom / k_vatom sync, :379-388)
+  if (eflag_atom) require(mtp_resident_peratom_host(ctx_, datom.stream, MTP_PERATOM_EATOM, eatom.data()), "eatom copy");
+  if (vflag_atom) require(mtp_resident_peratom_host(ctx_, datom.stream, MTP_PERATOM_VATOM, vatom.data()), "vatom copy");
+}
+
 void PairMTP::ev_setup(int eflag, int vflag)
 {
   // LAMMPS Pair::ev_setup bit semantics (pair.h); accumulators are zeroed each call
@@ -129,6 +164,10 @@ void PairMTP::compute(int eflag, int vflag)
 {
   if (!ctx_ || !list_set_) throw Error(MTP_ERR_STATE, "compute() before init_style()/set_neighbor_list()");
   ev_setup(eflag, vflag);
+  if (resident_) {
+    compute_resident(eflag, vflag, 0, nullptr, nullptr);
+    return;
+  }
   require(mtp_compute(ctx_, atom.x, atom.type, eflag, vflag, 0, atom.f, eflag_atom ? eatom.data() : nullptr,
                       vflag_atom ? vatom.data() : nullptr, &eng_vdwl, virial, nullptr, nullptr, nullptr),
           "mtp_compute");
@@ -181,6 +220,16 @@ void PairMTPExtrapolation::compute(int eflag, int vflag)
   if (!configuration_mode && (int) nbh_extrapolation_grades.size() < atom.nall)
     nbh_extrapolation_grades.resize((size_t) atom.nall, 0.0);   // :91-94 (grown, never shrunk)
   if (configuration_mode) std::fill(energy_ders_wrt_coeffs.begin(), energy_ders_wrt_coeffs.end(), 0.0);   // :97-98
+  if (resident_) {
+    // grades stay in HBM (KOKKOS/pair_mtp_extrapolation_kokkos.cpp:223-243 copies them only when asked); the maximum
+    // and, in configuration mode, the C-double candidate vector come back with the totals
+    compute_resident(eflag, vflag, 1, &max_grade, configuration_mode ? energy_ders_wrt_coeffs.data() : nullptr);
+    grades_on_device_ = !configuration_mode;
+    compile_grades();
+    if (mlip3_style) evaluate_grades();
+    return;
+  }
+  grades_on_device_ = false;
   require(mtp_compute(ctx_, atom.x, atom.type, eflag, vflag, 1, atom.f, eflag_atom ? eatom.data() : nullptr,
                       vflag_atom ? vatom.data() : nullptr, &eng_vdwl, virial,
                       configuration_mode ? nullptr : nbh_extrapolation_grades.data(), &max_grade,
@@ -222,6 +271,22 @@ void PairMTPExtrapolation::evaluate_grades()
 // header, its own lines, then the other ranks' in rank order (mtp_cfg_writer.hpp; the exchanges go through `red`).
 void PairMTPExtrapolation::write_config()
 {
+  int ncol = 0;
+  if (!configuration_mode) (void) extract_peratom("extrapolation", ncol);   // grades to the host when they are not there yet
+  std::vector<double> xh;
+  const double *x_host = atom.x;
+  if (resident_) {   // the record lists positions: one copy of the owned rows, only on the (rare) steps that write
+    xh.resize(3 * (size_t) atom.nlocal);
+    require(mtp_copy_to_host(ctx_, datom.stream, xh.data(), datom.d_x, xh.size() * sizeof(double)), "position copy");
+    x_host = xh.data();
+  }
+  std::vector<int> th;
+  const int *t_host = atom.type;
+  if (resident_) {
+    th.resize((size_t) atom.nlocal);
+    require(mtp_copy_to_host(ctx_, datom.stream, th.data(), datom.d_type, th.size() * sizeof(int)), "type copy");
+    t_host = th.data();
+  }
   CfgComm cc;
   cc.me = red.me;
   cc.nprocs = red.nprocs;
@@ -229,7 +294,7 @@ void PairMTPExtrapolation::write_config()
   cc.scan_sum = red.scan_sum;
   cc.send_to_root = red.send_to_root;
   cc.recv_on_root = red.recv_on_root;
-  cfg_write_record(preselected_file, cc, atom.natoms, box, configuration_mode, atom.nlocal, atom.type, atom.x,
+  cfg_write_record(preselected_file, cc, atom.natoms, box, configuration_mode, atom.nlocal, t_host, x_host,
                    configuration_mode ? nullptr : nbh_extrapolation_grades.data(), max_grade);
 }
 
@@ -246,6 +311,11 @@ void *PairMTPExtrapolation::extract_peratom(const char *str, int &ncol)
     if (configuration_mode)
       throw Error(MTP_ERR_STATE, "Please use the MLIP-3 style extrapolation for configuration mode MTPs!");
     ncol = 0;
+    if (grades_on_device_) {   // first request after a device-resident grade call: one copy, then the host array is current
+      if ((int) nbh_extrapolation_grades.size() < atom.nall) nbh_extrapolation_grades.resize((size_t) atom.nall, 0.0);
+      require(mtp_resident_peratom_host(ctx_, datom.stream, MTP_PERATOM_GRADES, nbh_extrapolation_grades.data()), "grades copy");
+      grades_on_device_ = false;
+    }
     return (void *) nbh_extrapolation_grades.data();
   }
   return nullptr;

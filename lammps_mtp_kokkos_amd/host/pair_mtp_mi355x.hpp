@@ -36,6 +36,26 @@ struct NeighListView {
   const int *numneigh = nullptr;
   const int *const *firstneigh = nullptr;
 };
+// What a KOKKOS-resident LAMMPS hands the /kk styles instead (KOKKOS/pair_mtp_kokkos.cpp:231-240: atomKK->sync,
+// x = atomKK->k_x.view<DeviceType>() ...; :236-239: k_list->d_numneigh, d_neighbors, d_ilist): device pointers and the
+// stream of the execution space.  ALL device work of a step -- the zeroing of the tallies, the force call, the copies
+// behind extract_peratom -- is ordered on `stream` (no second stream, no legacy null stream).
+struct DeviceAtomView {
+  const double *d_x = nullptr;   // [nall][3]
+  double *d_f = nullptr;         // [nall][3], accumulated
+  const int *d_type = nullptr;   // [nall], 1-based
+  int nlocal = 0, nall = 0;
+  long natoms = 0;
+  void *stream = nullptr;        // hipStream_t of the execution space (NULL: the context's own stream)
+  // host arrays LAMMPS reads per-atom results from (eatom / vatom of Pair); filled only when the flags ask, as the
+  // reference syncs k_eatom / k_vatom to the host only then (pair_mtp_kokkos.cpp:379-388)
+};
+struct DeviceNeighListView {     // padded 2-D view: element (i, jj) at d_neighbors[i * stride_i + jj * stride_jj]
+  int inum = 0;
+  const int *d_ilist = nullptr, *d_numneigh = nullptr, *d_neighbors = nullptr;
+  long long stride_i = 0, stride_jj = 0;
+  int maxneighs = 0;             // extent(1) of d_neighbors
+};
 using BoxView = CfgBox;   // domain->xprd ... for the .cfg writer (pair_mtp_extrapolation.cpp:449-451)
 // cross-rank reductions (LAMMPS: MPI_Allreduce on `world`); identity when unset (one rank)
 struct Reductions {
@@ -74,8 +94,16 @@ class PairMTP {
   virtual void compute(int eflag, int vflag);
 
   // bindings in place of the LAMMPS pointers
-  void bind(const AtomView &a) { atom = a; }
+  void bind(const AtomView &a)
+  {
+    atom = a;
+    resident_ = false;
+  }
   void set_neighbor_list(const NeighListView &l);   // call after every re-neighbouring
+  // the /kk styles' data path: positions, forces, types and the neighbour list stay on the device
+  void bind_device(const DeviceAtomView &a);
+  void set_neighbor_list_device(const DeviceNeighListView &l);
+  bool resident() const { return resident_; }
   void set_log(const LogSink &l) { log_ = l; }
   void set_rank(int me) { me_ = me; }               // comm->me: only rank 0 logs
 
@@ -97,6 +125,9 @@ class PairMTP {
   mtp_potential *pot_ = nullptr;
   mtp_context *ctx_ = nullptr;
   AtomView atom;
+  DeviceAtomView datom;
+  bool resident_ = false;   // bound to device views: compute() runs mtp_compute_resident
+  void compute_resident(int eflag, int vflag, int grade, double *max_grade, double *coeff_ders);
   bool list_set_ = false;
   int eflag_either = 0, eflag_global = 0, eflag_atom = 0, vflag_either = 0, vflag_global = 0, vflag_atom = 0;
 };
@@ -131,6 +162,7 @@ class PairMTPExtrapolation : public PairMTP {
   double select_threshold = 0, break_threshold = 0;
   std::FILE *preselected_file = nullptr;
   std::vector<double> nbh_extrapolation_grades, energy_ders_wrt_coeffs;
+  bool grades_on_device_ = false;   // the last grade call left the grades in the context's HBM: copied on extract_peratom
   Reductions red;
   BoxView box;
 };

@@ -1,12 +1,17 @@
 // LAMMPS plugin adapter: registers pair styles `mtp`, `mtp/kk`, `mtp/small/kk`,
 // `mtp/extrapolation`, `mtp/extrapolation/kk`, `mtp/extrapolation/small/kk` at run time
 // (`plugin load libmtp_mi355x_lammps.so`) and forwards the Pair virtuals the reference overrides
-// (/root/reference/LAMMPS/ML-MTP/pair_mtp.h:34-40, pair_mtp_extrapolation.h:35-38) to the C ABI
-// of libmtp_mi355x (include/mtp_mi355x.h).
+// (/root/reference/LAMMPS/ML-MTP/pair_mtp.h:34-40, pair_mtp_extrapolation.h:35-38).
+//
+// Thin by construction: every decision -- argument grammar, thresholds, grade steps, the .cfg record, the
+// device-resident /kk data path, which flags tally what -- lives in the host mirror (../host/pair_mtp_mi355x.{hpp,cpp}),
+// which IS compiled and exercised on the GPU by tests/cpp/test_pair_host.cpp.  This file only moves LAMMPS' pointers
+// into the mirror's views and its results back, and turns mtp_mi355x::Error into error->all / error->one.
 //
 // COMPILE-GATED: needs a LAMMPS source tree (not present in this repository's build image):
-//   hipcc/g++ -std=c++17 -fPIC -shared -I$LAMMPS_SOURCE_DIR/src -I$REPO/include \
-//       pair_mtp_mi355x_plugin.cpp -L$REPO/lammps_mtp_kokkos_amd -lmtp_mi355x -o libmtp_mi355x_lammps.so
+//   hipcc/g++ -std=c++17 -fPIC -shared -DLAMMPS_SOURCE_DIR_AVAILABLE [-DLMP_KOKKOS] -I$LAMMPS_SOURCE_DIR/src \
+//       [-I$LAMMPS_SOURCE_DIR/src/KOKKOS -I<kokkos include dirs>] -I$REPO/include pair_mtp_mi355x_plugin.cpp \
+//       -L$REPO/lammps_mtp_kokkos_amd -lpair_mtp_mi355x -lmtp_mi355x -o libmtp_mi355x_lammps.so
 // It has not been compiled against LAMMPS here; INTEGRATION.md lists what to check first.
 #ifdef LAMMPS_SOURCE_DIR_AVAILABLE
 
@@ -26,27 +31,35 @@
 #include "atom_kokkos.h"
 #include "atom_masks.h"
 #include "kokkos.h"
+#include "neigh_list_kokkos.h"
 #endif
 
 #include <cstring>
+#include <memory>
 #include <mpi.h>
 #include <string>
-#include <vector>
 
-#include "../host/mtp_cfg_writer.hpp"   // the .cfg record and the logmesg lines, shared with the host mirror
-#include "mtp_mi355x.h"
+#include "../host/pair_mtp_mi355x.hpp"
 
 namespace LAMMPS_NS {
 
 class PairMTPMI355X : public Pair {
+  using Mirror = mtp_mi355x::PairMTP;
+  using MirrorExt = mtp_mi355x::PairMTPExtrapolation;
+
  public:
-  // kk: one of the /kk styles (argument grammar of KOKKOS/pair_mtp_kokkos.cpp:113-117 and, with LMP_KOKKOS, device-resident x / f)
-  PairMTPMI355X(LAMMPS *lmp, int variant, bool ext, bool kk) : Pair(lmp), variant_(variant), ext_(ext), kk_(kk)
+  // kk: one of the /kk styles (argument grammar of KOKKOS/pair_mtp_kokkos.cpp:113-117 and, with LMP_KOKKOS,
+  // device-resident x / f / type / neighbour list)
+  PairMTPMI355X(LAMMPS *lmp, Mirror::Style style, bool ext, bool kk) : Pair(lmp), style_(style), ext_(ext), kk_(kk)
   {
     single_enable = 0;   // pair_mtp.cpp:37-40
     restartinfo = 0;
     one_coeff = 1;
     manybody_flag = 1;
+    // The pair style tallies its own virial on the raw vflag (pair_mtp.cpp:257) and never calls
+    // virial_fdotr_compute(); say so, as the reference's /kk styles do (KOKKOS/pair_mtp_kokkos.cpp:210), so that
+    // LAMMPS passes VIRIAL_PAIR instead of VIRIAL_FDOTR.  (The mirror tallies on either.)
+    no_virial_fdotr_compute = 1;
     if (ext_) {          // pair_mtp_extrapolation.cpp:42-44
       nextra = 1;
       pvector = new double[1];
@@ -60,240 +73,214 @@ class PairMTPMI355X : public Pair {
       memory->destroy(cutsq);
     }
     if (ext_) delete[] pvector;
-    if (preselected_file_) fclose(preselected_file_);
-    if (ctx_) mtp_context_destroy(ctx_);
-    if (pot_) mtp_potential_free(pot_);
   }
 
   void settings(int narg, char **arg) override
   {
-    // the reference's grammars, argument count for argument count:
-    //   mtp                        <file> [ignored ...]                      pair_mtp.cpp:285-297
-    //   mtp/kk, mtp/small/kk       <file> chunksize <N>   (exactly 3)         KOKKOS/pair_mtp_kokkos.cpp:113-117
-    //   mtp/extrapolation[...]     <file> [<out> <sel> <brk>] [chunksize <N>] pair_mtp_extrapolation.cpp:488-502
-    // chunksize only bounded the reference's spilled Jacobian: parsed, checked, ignored
-    int n = narg;
-    if (!ext_) {
-      if (!kk_) {
-        if (n < 1) error->all(FLERR, "Pair mtp only accepts 1 argument, the MTP potential file");
-        if (n > 1 && comm->me == 0)
-          utils::logmesg(lmp, "Pair mtp only accepts 1 argument, the MTP potential file. Ignoring excessive arguments!\n");
-      } else {
-        if (n != 3 || utils::lowercase(arg[1]) != "chunksize")
-          error->all(FLERR, "Pair mtp/kk requires 3 arguments {{potential_file} \"chunksize\" {{chunksize}}.");
-        (void) utils::inumeric(FLERR, arg[2], true, lmp);
-      }
+    // one rank per GPU: node-local rank -> device
+    int ndev = 1, local = 0;
+    MPI_Comm node;
+    MPI_Comm_split_type(world, MPI_COMM_TYPE_SHARED, 0, MPI_INFO_NULL, &node);
+    MPI_Comm_rank(node, &local);
+    MPI_Comm_free(&node);
+    if (const char *e = getenv("MTP_MI355X_GPUS_PER_NODE")) ndev = atoi(e);
+    const int device = local % (ndev > 0 ? ndev : 1);
+    if (ext_) {
+      auto *p = new MirrorExt(style_, device);
+      impl_.reset(p);
+      mtp_mi355x::Reductions red;   // compile_grades / write_config over `world` (pair_mtp_extrapolation.cpp:363-382, 401-479)
+      red.ctx = this;
+      red.me = comm->me;
+      red.nprocs = comm->nprocs;
+      red.sum = [](double *b, int n, void *c) { MPI_Allreduce(MPI_IN_PLACE, b, n, MPI_DOUBLE, MPI_SUM, ((PairMTPMI355X *) c)->world); };
+      red.max = [](double *b, int n, void *c) { MPI_Allreduce(MPI_IN_PLACE, b, n, MPI_DOUBLE, MPI_MAX, ((PairMTPMI355X *) c)->world); };
+      red.scan_sum = [](int v, void *c) {
+        int out = 0;
+        MPI_Scan(&v, &out, 1, MPI_INT, MPI_SUM, ((PairMTPMI355X *) c)->world);
+        return out;
+      };
+      red.send_to_root = [](const char *buf, size_t n, void *c) { MPI_Send(buf, (int) n, MPI_CHAR, 0, 0, ((PairMTPMI355X *) c)->world); };
+      red.recv_on_root = [](int src, std::string &out, void *c) {
+        MPI_Comm w = ((PairMTPMI355X *) c)->world;
+        MPI_Status st;
+        int n = 0;
+        MPI_Probe(src, 0, w, &st);
+        MPI_Get_count(&st, MPI_CHAR, &n);
+        out.resize((size_t) n);
+        MPI_Recv(out.empty() ? nullptr : &out[0], n, MPI_CHAR, src, 0, w, &st);
+      };
+      p->set_reductions(red);
     } else {
-      if ((n == 3 && utils::lowercase(arg[1]) == "chunksize") || (n == 6 && utils::lowercase(arg[4]) == "chunksize")) {
-        if (comm->me == 0) utils::logmesg(lmp, "Ignoring chunksize settings!\n");
-        n -= 2;
-      } else if (n != 1 && n != 4) {
-        error->all(FLERR, "Pair mtp/extrapolation only accepts 1 argument: {{potential_file}}. Or 4 arguments: "
-                          "{{potential_file}} {{output_file}}. {{selection_threshold}} {{break_threshold}}.");
-      }
-      if (n == 4) {
-        mlip3_style_ = true;
-        select_ = utils::numeric(FLERR, arg[2], true, lmp);
-        break_ = utils::numeric(FLERR, arg[3], true, lmp);
-      }
+      impl_.reset(new Mirror(style_, device));
+      impl_->set_rank(comm->me);
     }
-    char err[512] = "";
-    if (mtp_potential_load(arg[0], ext_ ? 1 : 0, &pot_, err, sizeof(err)) != MTP_OK) error->all(FLERR, err);
-    mtp_potential_get_info(pot_, &info_);
-    if (comm->me == 0) {   // the reference parses, hence logs, on rank 0 (pair_mtp.cpp:343, 383, 389)
-      utils::logmesg(lmp, mtp_mi355x::log_scaling(info_.scaling));
-      utils::logmesg(lmp, mtp_mi355x::log_species(info_.species_count));
-      if (ext_)            // pair_mtp_extrapolation.cpp:508-517
-        utils::logmesg(lmp, mtp_mi355x::log_extrapolation_mode(mlip3_style_, info_.configuration_mode != 0, select_, break_));
-    }
-    if (mlip3_style_ && comm->me == 0) {   // pair_mtp_extrapolation.cpp:519-521
-      preselected_file_ = fopen(arg[1], "w");
-      if (!preselected_file_) error->one(FLERR, "Cannot open {}", arg[1]);
-    }
-    const int np1 = info_.species_count + 1;   // pair_mtp.cpp:391-393, 455-456
+    mtp_mi355x::LogSink log;   // utils::logmesg (pair_mtp.cpp:383, 389; pair_mtp_extrapolation.cpp:508-517)
+    log.ctx = lmp;
+    log.write = [](const char *msg, void *c) { utils::logmesg((LAMMPS *) c, msg); };
+    impl_->set_log(log);
+    // the reference opens the file through utils::open_potential (pair_mtp.cpp:293, pair_mtp_extrapolation.cpp:504):
+    // resolve the name the same way (LAMMPS_POTENTIALS search path) before the library opens it
+    std::string path = utils::get_potential_file_path(arg[0]);
+    if (path.empty()) error->all(FLERR, "Cannot open MTP potential file {}", arg[0]);
+    std::vector<char *> av(arg, arg + narg);
+    av[0] = &path[0];
+    guard([&] { impl_->settings(narg, av.data()); });
+    const int np1 = impl_->info.species_count + 1;   // pair_mtp.cpp:391-393, 455-456
     memory->create(setflag, np1, np1, "pair:setflag");
     memory->create(cutsq, np1, np1, "pair:cutsq");
     for (int i = 1; i < np1; i++)
       for (int j = 1; j < np1; j++) {
         setflag[i][j] = 1;
-        cutsq[i][j] = info_.max_cutoff * info_.max_cutoff;
+        cutsq[i][j] = impl_->info.max_cutoff * impl_->info.max_cutoff;
       }
     allocated = 1;
   }
-  void coeff(int narg, char **) override
+  void coeff(int narg, char **arg) override
   {
-    if (narg != 2) error->all(FLERR, "Only \"pair_coeff * *\" is permitted");
+    guard([&] { impl_->coeff(narg, arg); });
   }
   void init_style() override
   {
-    if (force->newton_pair != 1) error->all(FLERR, "Pair style MTP requires Newton Pair on");
-    neighbor->add_request(this, NeighConst::REQ_FULL);
-    if (!ctx_) {
-      char err[512] = "";
-      int ndev = 1;   // one rank per GPU: local rank -> device
-      MPI_Comm node;
-      MPI_Comm_split_type(world, MPI_COMM_TYPE_SHARED, 0, MPI_INFO_NULL, &node);
-      int local = 0;
-      MPI_Comm_rank(node, &local);
-      MPI_Comm_free(&node);
-      if (const char *e = getenv("MTP_MI355X_GPUS_PER_NODE")) ndev = atoi(e);
-      if (mtp_context_create(pot_, local % (ndev > 0 ? ndev : 1), &ctx_, err, sizeof(err)) != MTP_OK)
-        error->all(FLERR, err);
-      mtp_context_set_variant(ctx_, variant_);
-    }
+    guard([&] { impl_->init_style(force->newton_pair); });
+    neighbor->add_request(this, NeighConst::REQ_FULL);   // pair_mtp.cpp:317-318
   }
   double init_one(int i, int j) override
   {
     if (setflag[i][j] == 0) error->all(FLERR, "Not all pair coeffs are set. See types {}-{}.", i, j);
-    return info_.max_cutoff;
+    return impl_->info.max_cutoff;
   }
+
   void compute(int eflag, int vflag) override
   {
     ev_init(eflag, vflag);
     const int nall = atom->nlocal + atom->nghost;
-    if (neighbor->ago == 0 || !list_sent_) {   // list was rebuilt this step
-      check(mtp_set_neighbors(ctx_, list->inum, list->ilist, list->numneigh, list->firstneigh, nall));
-      list_sent_ = true;
+    const bool relist = neighbor->ago == 0 || !list_sent_;   // the list was rebuilt this step
+    if (ext_) {
+      auto *p = static_cast<MirrorExt *>(impl_.get());
+      p->extrapolation_flag = extrapolation_flag_;
+      mtp_mi355x::BoxView b;
+      b.xprd = domain->xprd;
+      b.yprd = domain->yprd;
+      b.zprd = domain->zprd;
+      b.xy = domain->xy;
+      b.xz = domain->xz;
+      b.yz = domain->yz;
+      p->set_box(b);
     }
-    const int grade = ext_ && (extrapolation_flag_ || mlip3_style_);   // pair_mtp_extrapolation.cpp:71
-    const bool cfg = info_.configuration_mode != 0;
-    if (grade && !cfg && (int) grades_.size() < nall) grades_.resize(nall, 0.0);   // :91-94
-    if (grade && cfg) cders_.assign(info_.coeff_count, 0.0);                        // :97-98
-    double mg = 0.0;
 #ifdef LMP_KOKKOS
-    // KOKKOS-resident positions and forces (KOKKOS/pair_mtp_kokkos.cpp:231-240: atomKK->sync / modified): no PCIe
-    // copy of x and f.  Per-atom outputs and grades still go through the host arrays below, so this path is taken
-    // when the step asks for global tallies only -- every step of a production run.
-    if (kk_ && lmp->kokkos && !eflag_atom && !vflag_atom && !grade) {
+    // KOKKOS-resident atoms AND list (KOKKOS/pair_mtp_kokkos.cpp:231-240): nothing crosses PCIe except the totals --
+    // also on grade steps and per-atom-tally steps (the mirror copies eatom / vatom only when the flags ask and the
+    // grades only on extract_peratom, as pair_mtp_extrapolation_kokkos.cpp:223-243 does).  One stream for the whole
+    // step: the execution space's, so the zeroing, atomKK's syncs and the force kernel are ordered.
+    if (kk_ && lmp->kokkos) {
       auto *akk = (AtomKokkos *) atom;
       akk->sync(Device, X_MASK | F_MASK | TYPE_MASK);
-      if (!d_ev_) check(hipMalloc((void **) &d_ev_, 8 * sizeof(double)) == hipSuccess ? MTP_OK : MTP_ERR_DEVICE);
-      hipMemsetAsync(d_ev_, 0, 8 * sizeof(double), nullptr);
-      check(mtp_compute_device(ctx_, nullptr, akk->k_x.d_view.data(), akk->k_type.d_view.data(), eflag, vflag, 0,
-                               akk->k_f.d_view.data(), nullptr, nullptr, d_ev_, nullptr, nullptr, nullptr));
-      check(mtp_synchronize(ctx_, nullptr));
-      double ev[8];
-      hipMemcpy(ev, d_ev_, sizeof(ev), hipMemcpyDeviceToHost);
-      if (eflag_global) eng_vdwl += ev[0];
-      if (vflag_either)
-        for (int q = 0; q < 6; q++) virial[q] += ev[1 + q];
+      mtp_mi355x::DeviceAtomView dv;
+      dv.d_x = akk->k_x.d_view.data();
+      dv.d_f = akk->k_f.d_view.data();
+      dv.d_type = akk->k_type.d_view.data();
+      dv.nlocal = atom->nlocal;
+      dv.nall = nall;
+      dv.natoms = (long) atom->natoms;
+      dv.stream = (void *) Kokkos::HIP().hip_stream();
+      impl_->bind_device(dv);
+      if (relist) {
+        auto *kl = static_cast<NeighListKokkos<LMPDeviceType> *>(list);
+        mtp_mi355x::DeviceNeighListView lv;
+        lv.inum = list->inum;
+        lv.d_ilist = kl->d_ilist.data();
+        lv.d_numneigh = kl->d_numneigh.data();
+        lv.d_neighbors = kl->d_neighbors.data();
+        lv.stride_i = (long long) kl->d_neighbors.stride(0);
+        lv.stride_jj = (long long) kl->d_neighbors.stride(1);
+        lv.maxneighs = (int) kl->d_neighbors.extent(1);
+        guard([&] { impl_->set_neighbor_list_device(lv); });
+        list_sent_ = true;
+      }
+      guard_one([&] { impl_->compute(eflag, vflag); });
       akk->modified(Device, F_MASK);
+      collect(eflag, vflag, nall);
       return;
     }
 #endif
-    check(mtp_compute(ctx_, &atom->x[0][0], atom->type, eflag, vflag, grade, &atom->f[0][0],
-                      eflag_atom ? eatom : nullptr, vflag_atom ? &vatom[0][0] : nullptr, &eng_vdwl, virial,
-                      grade && !cfg ? grades_.data() : nullptr, &mg, grade && cfg ? cders_.data() : nullptr));
-    if (!grade) return;
-    // compile_grades, pair_mtp_extrapolation.cpp:363-382
-    if (cfg) {
-      MPI_Allreduce(MPI_IN_PLACE, cders_.data(), info_.coeff_count, MPI_DOUBLE, MPI_SUM, world);
-      mtp_cfg_grade(pot_, cders_.data(), &mg);
-      mg = atom->natoms > 0 ? mg / atom->natoms : 0.0;
-    } else {
-      MPI_Allreduce(MPI_IN_PLACE, &mg, 1, MPI_DOUBLE, MPI_MAX, world);
+    mtp_mi355x::AtomView av;
+    av.x = &atom->x[0][0];
+    av.f = &atom->f[0][0];
+    av.type = atom->type;
+    av.nlocal = atom->nlocal;
+    av.nall = nall;
+    av.natoms = (long) atom->natoms;
+    impl_->bind(av);
+    if (relist) {
+      mtp_mi355x::NeighListView lv{list->inum, list->ilist, list->numneigh, list->firstneigh};
+      guard([&] { impl_->set_neighbor_list(lv); });
+      list_sent_ = true;
     }
-    if (comm->me == 0) pvector[0] = mg;
-    if (!mlip3_style_) return;
-    // evaluate_grades, :387-397
-    if (mg >= select_) write_config(mg);
-    if (mg >= break_ && comm->me == 0) {
-      if (preselected_file_) {
-        fflush(preselected_file_);
-        fclose(preselected_file_);
-        preselected_file_ = nullptr;
-      }
-      error->one(FLERR, "Exceeded Break Threshold: {:.5f}. Terminating simulation.\n", mg);
-    }
+    guard_one([&] { impl_->compute(eflag, vflag); });
+    collect(eflag, vflag, nall);
   }
+
   void *extract(const char *str, int &dim) override
   {
     dim = 0;
-    if (ext_ && strcmp(str, "extrapolation_flag") == 0) return (void *) &extrapolation_flag_;
+    if (ext_ && strcmp(str, "extrapolation_flag") == 0) return (void *) &extrapolation_flag_;   // pair_mtp_extrapolation.cpp:624-631
     return nullptr;
   }
   void *extract_peratom(const char *str, int &ncol) override
   {
-    if (ext_ && strcmp(str, "extrapolation") == 0) {
-      if (info_.configuration_mode)
-        error->one(FLERR, "Please use the MLIP-3 style extrapolation for configuration mode MTPs!");
-      ncol = 0;
-      return (void *) grades_.data();
-    }
-    return nullptr;
+    if (!ext_) return nullptr;
+    void *p = nullptr;
+    guard_one([&] { p = static_cast<MirrorExt *>(impl_.get())->extract_peratom(str, ncol); });   // :641-652
+    return p;
   }
 
  private:
-  // write_config, pair_mtp_extrapolation.cpp:401-479: the shared writer with MPI behind its three exchanges
-  struct MpiCtx {
-    MPI_Comm world;
-  };
-  static int scan_sum(int v, void *c)
+  // results of the mirror into the arrays LAMMPS reads (pair.h): eng_vdwl / virial accumulate, eatom / vatom were
+  // zeroed by ev_init and receive the call's values, pvector[0] on rank 0 only (pair_mtp_extrapolation.cpp:381)
+  void collect(int, int, int nall)
   {
-    int out = 0;
-    MPI_Scan(&v, &out, 1, MPI_INT, MPI_SUM, ((MpiCtx *) c)->world);
-    return out;
+    eng_vdwl += impl_->eng_vdwl;
+    for (int q = 0; q < 6; q++) virial[q] += impl_->virial[q];
+    if (eflag_atom)
+      for (int i = 0; i < nall; i++) eatom[i] += impl_->eatom[i];
+    if (vflag_atom)
+      for (int i = 0; i < nall; i++)
+        for (int q = 0; q < 6; q++) vatom[i][q] += impl_->vatom[6 * (size_t) i + q];
+    if (ext_ && comm->me == 0) pvector[0] = static_cast<MirrorExt *>(impl_.get())->pvector[0];
   }
-  static void send_to_root(const char *buf, size_t n, void *c)
+  template <class F> void guard(F &&fn)   // errors every rank meets: error->all
   {
-    MPI_Send(buf, (int) n, MPI_CHAR, 0, 0, ((MpiCtx *) c)->world);
+    try {
+      fn();
+    } catch (const mtp_mi355x::Error &e) {
+      error->all(FLERR, e.what());
+    }
   }
-  static void recv_on_root(int src, std::string &out, void *c)
+  template <class F> void guard_one(F &&fn)   // per-rank errors (device failures, the break threshold on rank 0): error->one
   {
-    MPI_Status st;
-    int n = 0;
-    MPI_Probe(src, 0, ((MpiCtx *) c)->world, &st);
-    MPI_Get_count(&st, MPI_CHAR, &n);
-    out.resize((size_t) n);
-    MPI_Recv(out.empty() ? nullptr : &out[0], n, MPI_CHAR, src, 0, ((MpiCtx *) c)->world, &st);
+    try {
+      fn();
+    } catch (const mtp_mi355x::Error &e) {
+      error->one(FLERR, e.what());
+    }
   }
-  void write_config(double mg)
-  {
-    MpiCtx mc{world};
-    mtp_mi355x::CfgComm cc;
-    cc.me = comm->me;
-    cc.nprocs = comm->nprocs;
-    cc.ctx = &mc;
-    cc.scan_sum = scan_sum;
-    cc.send_to_root = send_to_root;
-    cc.recv_on_root = recv_on_root;
-    mtp_mi355x::CfgBox b;
-    b.xprd = domain->xprd;
-    b.yprd = domain->yprd;
-    b.zprd = domain->zprd;
-    b.xy = domain->xy;
-    b.xz = domain->xz;
-    b.yz = domain->yz;
-    mtp_mi355x::cfg_write_record(preselected_file_, cc, (long) atom->natoms, b, info_.configuration_mode != 0, list->inum,
-                                 atom->type, &atom->x[0][0], info_.configuration_mode ? nullptr : grades_.data(), mg);
-  }
-  void check(int rc)
-  {
-    if (rc != MTP_OK) error->one(FLERR, "libmtp_mi355x: {}", ctx_ ? mtp_last_error(ctx_) : "device error");
-  }
-  int variant_;
-  bool ext_, kk_, mlip3_style_ = false, list_sent_ = false;
-  int extrapolation_flag_ = 0;
-  double select_ = 0, break_ = 0;
-  FILE *preselected_file_ = nullptr;
-  double *d_ev_ = nullptr;
-  mtp_potential *pot_ = nullptr;
-  mtp_context *ctx_ = nullptr;
-  mtp_potential_info info_{};
-  std::vector<double> grades_, cders_;
+  Mirror::Style style_;
+  bool ext_, kk_, list_sent_ = false;
+  int extrapolation_flag_ = 0;   // set by `fix pair` through extract()
+  std::unique_ptr<Mirror> impl_;
 };
 
 }   // namespace LAMMPS_NS
 
 using namespace LAMMPS_NS;
-#define MTP_CREATOR(fn, variant, ext, kk) \
-  static Pair *fn(LAMMPS *lmp) { return new PairMTPMI355X(lmp, variant, ext, kk); }
-MTP_CREATOR(make_mtp, MTP_VARIANT_AUTO, false, false)
-MTP_CREATOR(make_mtp_kk, MTP_VARIANT_LARGE, false, true)
-MTP_CREATOR(make_mtp_small, MTP_VARIANT_SMALL, false, true)
-MTP_CREATOR(make_ext, MTP_VARIANT_AUTO, true, false)
-MTP_CREATOR(make_ext_kk, MTP_VARIANT_LARGE, true, true)
-MTP_CREATOR(make_ext_small, MTP_VARIANT_SMALL, true, true)
+#define MTP_CREATOR(fn, style, ext, kk) \
+  static Pair *fn(LAMMPS *lmp) { return new PairMTPMI355X(lmp, mtp_mi355x::PairMTP::style, ext, kk); }
+MTP_CREATOR(make_mtp, MTP, false, false)
+MTP_CREATOR(make_mtp_kk, MTP_KK, false, true)
+MTP_CREATOR(make_mtp_small, MTP_SMALL_KK, false, true)
+MTP_CREATOR(make_ext, MTP, true, false)
+MTP_CREATOR(make_ext_kk, MTP_KK, true, true)
+MTP_CREATOR(make_ext_small, MTP_SMALL_KK, true, true)
 
 extern "C" void lammpsplugin_init(void *lmp, void *handle, void *regfunc)
 {

@@ -6,6 +6,10 @@
 //   test_pair_host cfg <system> <outdir> <0|1>            .cfg records of 1-, 2- and 3-rank jobs (no GPU needed)
 //   test_pair_host run    <style> <system> <out> <pair_style args...>
 //   test_pair_host runext <style> <system> <out> <pair_style args...>
+//   test_pair_host rundev / runextdev ...                 the same through the /kk styles' data path: x, f, type and
+//                                                         the padded 2-D neighbour view resident on the device
+//                                                         (DeviceAtomView / DeviceNeighListView), vflag = VIRIAL_FDOTR
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -13,6 +17,8 @@
 #include <iostream>
 #include <string>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>   // host API only: staging of the device views a KOKKOS-resident LAMMPS would own
 
 #include "../../lammps_mtp_kokkos_amd/host/pair_mtp_mi355x.hpp"
 
@@ -49,6 +55,75 @@ struct System {
   }
 };
 
+
+// The device views of a KOKKOS-resident LAMMPS, staged by hand: x / f / type, d_ilist, d_numneigh (indexed by atom) and
+// the padded LayoutLeft view d_neighbors(i, jj) = base[i + jj * nall] with LAMMPS' special-bond bits in the entries and
+// garbage in the padding; everything on one non-blocking stream (the "execution space instance").
+struct DeviceSystem {
+  double *d_x = nullptr, *d_f = nullptr;
+  int *d_type = nullptr, *d_ilist = nullptr, *d_numneigh = nullptr, *d_neighbors = nullptr;
+  hipStream_t stream = nullptr;
+  int maxneighs = 0;
+  static void ok(hipError_t e, const char *what)
+  {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+  }
+  template <class T> static T *up(const std::vector<T> &v)
+  {
+    T *d = nullptr;
+    ok(hipMalloc((void **) &d, std::max<size_t>(v.size(), 1) * sizeof(T)), "hipMalloc");
+    if (!v.empty()) ok(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy");
+    return d;
+  }
+  void stage(const System &s)
+  {
+    ok(hipSetDevice(0), "hipSetDevice");
+    ok(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+    d_x = up(s.x);
+    d_f = up(s.f);
+    d_type = up(s.type);
+    d_ilist = up(s.ilist);
+    d_numneigh = up(s.numneigh);
+    for (int i = 0; i < s.nlocal; i++) maxneighs = std::max(maxneighs, s.numneigh[i]);
+    maxneighs += 3;
+    std::vector<int> view((size_t) s.nall * maxneighs);
+    for (size_t k = 0; k < view.size(); k++) view[k] = (int) ((k * 2654435761u) % (unsigned) s.nall);   // padding: garbage ids
+    for (int i = 0; i < s.nlocal; i++)
+      for (int jj = 0; jj < s.numneigh[i]; jj++)
+        view[(size_t) i + (size_t) jj * s.nall] = s.rows[i][jj] | (int) ((unsigned) ((i + jj) & 3) << 30);   // special bits
+    d_neighbors = up(view);
+  }
+  DeviceAtomView atoms(const System &s) const
+  {
+    DeviceAtomView a;
+    a.d_x = d_x;
+    a.d_f = d_f;
+    a.d_type = d_type;
+    a.nlocal = s.nlocal;
+    a.nall = s.nall;
+    a.natoms = s.nlocal;
+    a.stream = stream;
+    return a;
+  }
+  DeviceNeighListView list(const System &s) const
+  {
+    DeviceNeighListView l;
+    l.inum = s.nlocal;
+    l.d_ilist = d_ilist;
+    l.d_numneigh = d_numneigh;
+    l.d_neighbors = d_neighbors;
+    l.stride_i = 1;
+    l.stride_jj = s.nall;
+    l.maxneighs = maxneighs;
+    return l;
+  }
+  void forces_to(System &s) const
+  {
+    ok(hipStreamSynchronize(stream), "sync");
+    ok(hipMemcpy(s.f.data(), d_f, s.f.size() * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy f");
+  }
+  void zero_forces(const System &s) const { ok(hipMemsetAsync(d_f, 0, s.f.size() * sizeof(double), stream), "memset f"); }
+};
 
 static PairMTP::Style style_of(const std::string &s)
 {
@@ -200,9 +275,15 @@ int main(int argc, char **argv)
       std::fprintf(stderr, "usage: see the header of this file\n");
       return 2;
     }
-    const bool ext = !std::strcmp(argv[1], "runext");
+    const bool dev = !std::strcmp(argv[1], "rundev") || !std::strcmp(argv[1], "runextdev");
+    const bool ext = !std::strcmp(argv[1], "runext") || !std::strcmp(argv[1], "runextdev");
     System s;
     s.read(argv[3]);
+    DeviceSystem ds;
+    if (dev) ds.stage(s);
+    // VIRIAL_FDOTR (2): what LAMMPS passes with newton_pair on unless the style opts out; the pair style must tally
+    // its own virial on the raw flag (pair_mtp.cpp:257)
+    const int vflag_run = dev ? (2 | 4) : 4;
     AtomView av;
     av.x = s.x.data();
     av.f = s.f.data();
@@ -219,11 +300,17 @@ int main(int argc, char **argv)
       PairMTP p(style_of(argv[2]));
       p.settings(argc - 5, argv + 5);
       p.coeff(2, cf);
-      p.bind(av);
       p.init_style(1);
       double cut = p.init_one(1, 1);
-      p.set_neighbor_list(lv);
-      p.compute(3, 4);
+      if (dev) {
+        p.bind_device(ds.atoms(s));
+        p.set_neighbor_list_device(ds.list(s));
+      } else {
+        p.bind(av);
+        p.set_neighbor_list(lv);
+      }
+      p.compute(3, vflag_run);
+      if (dev) ds.forces_to(s);
       out << p.eng_vdwl << " " << cut << "\n";
       for (int q = 0; q < 6; q++) out << p.virial[q] << (q == 5 ? "\n" : " ");
       for (int i = 0; i < s.nall; i++)
@@ -232,19 +319,25 @@ int main(int argc, char **argv)
       PairMTPExtrapolation p(style_of(argv[2]));
       p.settings(argc - 5, argv + 5);
       p.coeff(2, cf);
-      p.bind(av);
       BoxView b;
       b.xprd = s.box[0];
       b.yprd = s.box[1];
       b.zprd = s.box[2];
       p.set_box(b);
       p.init_style(1);
-      p.set_neighbor_list(lv);
+      if (dev) {
+        p.bind_device(ds.atoms(s));
+        p.set_neighbor_list_device(ds.list(s));
+      } else {
+        p.bind(av);
+        p.set_neighbor_list(lv);
+      }
       int dim = 0, ncol = 0;
       // no grade requested: plain forces (pair_mtp_extrapolation.cpp:71-74) unless MLIP-3 style
       p.compute(3, 0);
       const double e_plain = p.eng_vdwl;
       std::fill(s.f.begin(), s.f.end(), 0.0);
+      if (dev) ds.zero_forces(s);
       *(int *) p.extract("extrapolation_flag", dim) = 1;   // what `fix pair` does
       bool stopped = false;
       std::string why;

@@ -131,3 +131,70 @@ def test_extrapolation_style_fix_pair_protocol_and_cfg_file(tmp_path):
     r = subprocess.run([EXE, "runext", "mtp/extrapolation", sysf, outf, potf, cfgf, "%.6f" % (0.5 * mg), "%.6f" % (0.9 * mg)],
                        capture_output=True, text=True)
     assert "Exceeded Break Threshold" in r.stdout + r.stderr
+
+
+# ---- the /kk styles' data path: x, f, type and the padded 2-D neighbour view resident on the device --------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("style,extra", [("mtp/kk", ["chunksize", "32768"]), ("mtp/small/kk", ["chunksize", "4096"])])
+def test_kk_styles_device_resident_step_with_fdotr_vflag(tmp_path, style, extra):
+    """DeviceAtomView + DeviceNeighListView (what LAMMPS-KOKKOS hands the reference's /kk styles,
+    KOKKOS/pair_mtp_kokkos.cpp:231-240): list compacted on the device from the LayoutLeft view, one stream for the whole
+    step, eatom / vatom copied back because the step asked, and the global virial tallied although vflag = VIRIAL_FDOTR
+    | VIRIAL_ATOM (the pair style tallies on the raw flag, pair_mtp.cpp:257)."""
+    from oracle.pyoracle import Oracle
+    _build()
+    pos, box = mtpgen.bcc_lattice(4, 4, 4)
+    s = periodic_system(pos, box, None, 7.0)
+    sysf, outf = str(tmp_path / "sys.txt"), str(tmp_path / "out.txt")
+    _write_system(sysf, s)
+    potf = os.path.join(POT, "W_L16.mtp")
+    r = subprocess.run([EXE, "rundev", style, sysf, outf, potf] + extra, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = open(outf).read().split("\n")
+    e, cut = map(float, lines[0].split())
+    vir = np.array(lines[1].split(), float)
+    arr = np.array([l.split() for l in lines[2:2 + s.nall]], float)
+    want = Oracle(potf).compute(s.x, s.types, s.ilist, s.first, s.neigh)
+    assert cut == 5.0 and abs(e - want["energy"]) < 1e-9
+    assert np.abs(arr[:, :3] - want["f"]).max() < 1e-9
+    assert np.abs(arr[:, 3] - want["eatom"]).max() < 1e-10
+    assert np.abs(vir).max() > 1e-3 and np.abs(vir - want["virial"]).max() < 1e-8        # not dropped under VIRIAL_FDOTR
+
+
+@pytest.mark.gpu
+def test_extrapolation_kk_style_keeps_grades_on_the_device_until_asked(tmp_path):
+    """mtp/extrapolation/kk through the device-resident path: grade steps run on the device views too (the reference
+    copies grades to the host only when asked, KOKKOS/pair_mtp_extrapolation_kokkos.cpp:223-243): pvector[0], the
+    grades behind extract_peratom and the .cfg record (positions copied only for the record) against the oracle."""
+    from oracle.pyoracle import Oracle
+    _build()
+    pos, box = mtpgen.bcc_lattice(3, 3, 3)
+    s = periodic_system(pos, box, None, 7.0)
+    sysf, outf, cfgf = str(tmp_path / "sys.txt"), str(tmp_path / "out.txt"), str(tmp_path / "sel.cfg")
+    _write_system(sysf, s)
+    potf = os.path.join(POT, "W_L16_nbh.almtp")
+    want = Oracle(potf, selection=True).compute(s.x, s.types, s.ilist, s.first, s.neigh, extrapolation=True)
+    mg = want["max_grade"]
+    r = subprocess.run([EXE, "runextdev", "mtp/extrapolation/kk", sysf, outf, potf, cfgf, "%.6f" % (0.5 * mg),
+                        "%.6f" % (2 * mg), "chunksize", "1024"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = open(outf).read().split("\n")
+    e, e_plain, pv, stopped = lines[0].split()
+    assert abs(float(e) - want["energy"]) < 1e-9 and abs(float(e_plain) - want["energy"]) < 1e-9
+    assert abs(float(pv) - mg) < 1e-9 * max(1, mg) and stopped == "0"
+    g = np.array(lines[1:1 + s.nlocal], float)
+    assert np.abs(g - want["grades"][: s.nlocal]).max() < 1e-9 * max(1, mg)
+    cfg = open(cfgf).read()
+    assert cfg.count("BEGIN_CFG") == 2 and cfg.count("END_CFG") == 2
+    rec = cfg.split("END_CFG")[0].split("\n")
+    first = rec[8].split("\t")
+    assert first[0] == "1" and first[1] == "0" and first[5] == "%.5f" % want["grades"][0]
+    assert first[2:5] == ["%.6f" % v for v in s.x[0]]
+    # plain 1-argument form driven by `fix pair` (extrapolation_flag through extract): no file, grades on request
+    r = subprocess.run([EXE, "runextdev", "mtp/extrapolation/small/kk", sysf, outf, potf], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = open(outf).read().split("\n")
+    assert abs(float(lines[0].split()[2]) - mg) < 1e-9 * max(1, mg)
+    g = np.array(lines[1:1 + s.nlocal], float)
+    assert np.abs(g - want["grades"][: s.nlocal]).max() < 1e-9 * max(1, mg)
