@@ -94,7 +94,7 @@ struct mtp_context {
   DevBuf<unsigned long long> d_stamps;
   // launch geometry
   struct Layout {   // per-atom LDS image, offsets in doubles (MtpDevParams: dg_mode, pow_row, dg_off, off_*)
-    int mode = 0, pow_row = 0, dg_off = 0, off_m = 0, off_d = 0, off_coef = 0, off_nb = 0, m_doubles = 0;
+    int mode = 0, pow_row = 0, dg_off = 0, fp_row = 0, off_m = 0, off_d = 0, off_coef = 0, off_nb = 0, m_doubles = 0;
   };
   struct LaunchPlan {
     Layout layout;
@@ -157,18 +157,20 @@ void mtp_context::plan()
     keep.off_coef = trows;
     keep.m_doubles = m_keep;
     keep.off_nb = trows + std::max(3 * P * MTP_PITCH, d_doubles + m_keep);
-    //   lean     [g rows | overlay]; the dg rows join the overlay behind the coefficient blocks and are written ahead
-    //            of the force phase from radial derivatives the tile build parked in registers (Mu <= 4): 12.4
-    //            instead of 15.7 KB per atom at level 16
+    //   nodg     [g rows | overlay] (Mu <= 4): no dg rows; Mu rows f'_mu (written ahead of the force phase from radial
+    //            derivatives the tile build parked in registers) sit behind the coefficient blocks: 11.7 instead of
+    //            15.7 KB per atom at level 16, and neither the 16 dg rows nor a second evaluation of the radial functions
+    const int Mu_ = p.radial_func_count;
+    const bool nodg_ok = Mu_ <= 4;
     Layout lean = keep;
     lean.mode = 1;
     lean.pow_row = p.slot_count;
-    lean.dg_off = grows + p.coef_total;
+    lean.dg_off = 0;
     lean.off_m = grows;
     lean.off_d = grows + m_keep;
     lean.off_coef = grows;
-    lean.off_nb = grows + std::max(std::max(3 * P * MTP_PITCH, d_doubles + m_keep), p.coef_total + grows);
-    const bool lean_ok = p.radial_func_count <= 4;
+    lean.fp_row = (grows + p.coef_total + MTP_PITCH - 1) / MTP_PITCH;
+    lean.off_nb = std::max(grows + std::max(3 * P * MTP_PITCH, d_doubles + m_keep), (lean.fp_row + Mu_) * MTP_PITCH);
     //   rebuild  everything overlays everything (many moments): first table build = g rows and power rows only;
     //            moments and adjoints then take the front of the region; ahead of the force phase the g and dg rows
     //            are built again (coefficient blocks behind them, D[0, B) in front).  One more pass over the
@@ -184,6 +186,14 @@ void mtp_context::plan()
     reb.m_doubles = m_reb;
     reb.off_nb = std::max(std::max(grows + 3 * P * MTP_PITCH, trows + p.coef_total), d_doubles + m_reb);
     const bool reb_ok = trows >= p.alpha_index_basic_count;
+    //   rebuild without dg rows (Mu <= 4): the second build writes the g rows only, the f' rows follow the coefficients
+    Layout rebn = reb;
+    rebn.mode = 3;
+    rebn.dg_off = 0;
+    rebn.off_coef = grows;
+    rebn.fp_row = (grows + p.coef_total + MTP_PITCH - 1) / MTP_PITCH;
+    rebn.off_nb = std::max(std::max(grows + 3 * P * MTP_PITCH, (rebn.fp_row + Mu_) * MTP_PITCH), d_doubles + m_reb);
+    const bool rebn_ok = nodg_ok && grows >= p.alpha_index_basic_count;
     auto bytes_of = [&](const Layout &y) { return ((size_t) y.off_nb * 8 + tail + 15) / 16 * 16; };
     // registers: 8 wavefronts per CU (2 per SIMD at <= 256 VGPRs) in workgroups of up to 8, or -- for the table
     // shapes that have the 168-VGPR build -- 12 (3 per SIMD).  Measured on MI355X: a workgroup is only admitted when
@@ -208,18 +218,19 @@ void mtp_context::plan()
       return 0;
     };
     const bool fine = variant == MTP_VARIANT_SMALL || (variant == MTP_VARIANT_AUTO && inum < num_cus * 16);
-    // candidates in order of preference at equal occupancy: keep (no extra work), lean (a few flops), rebuild
-    std::vector<const Layout *> cands = {&keep};
-    if (lean_ok) cands.push_back(&lean);
+    // candidates in order of preference at equal occupancy: nodg (least work), keep, then the rebuilding ones
+    std::vector<const Layout *> cands;
+    if (nodg_ok) cands.push_back(&lean);
+    cands.push_back(&keep);
+    if (rebn_ok) cands.push_back(&rebn);
     if (reb_ok) cands.push_back(&reb);
-    if (const char *e = std::getenv("MTP_LAYOUT")) {   // tuning override (benchmarks, tests): keep | lean | rebuild
+    if (const char *e = std::getenv("MTP_LAYOUT")) {   // tuning override (benchmarks, tests): keep | nodg | rebuild | rebuild-nodg
       const std::string v(e);
       if (v == "keep") cands = {&keep};
-      else if (v == "lean" && lean_ok) cands = {&lean};
+      else if ((v == "nodg" || v == "lean") && nodg_ok) cands = {&lean};
       else if (v == "rebuild" && reb_ok) cands = {&reb};
-    } else if (const char *e2 = std::getenv("MTP_REBUILD_TABLES")) {   // older spelling of the same override
-      if (std::atoi(e2) != 0 && reb_ok) cands = {&reb};
-      else cands = {&keep};
+      else if (v == "rebuild-nodg" && rebn_ok) cands = {&rebn};
+      else if (v == "rebuild" && rebn_ok) cands = {&rebn};
     }
     // the 3-per-SIMD build pays when there are atoms enough to fill twelve wavefronts per CU
     bool has3 = mtp_wave_kernel_has_wps3(p.fwd_block_count, P);
@@ -233,7 +244,8 @@ void mtp_context::plan()
     int wps = 2, w3 = 0, pick_waves = 0;
     for (const Layout *y : cands) {
       int v = best2(bytes_of(*y)), vw3 = 0;
-      if (has3 && (vw3 = shape3(bytes_of(*y))) > 0) v = 12;
+      // (the 3-per-SIMD build carries the dg-free force phase only)
+      if (has3 && (y->mode & 1) && (vw3 = shape3(bytes_of(*y))) > 0) v = 12;
       if (v > pick_waves) {
         pick = y;
         pick_waves = v;
@@ -243,7 +255,7 @@ void mtp_context::plan()
     }
     if (!pick) return 0;
     L.layout = *pick;
-    L.rebuild = pick->mode == 2;
+    L.rebuild = (pick->mode & 2) != 0;
     L.wps = wps;
     L.m_doubles = pick->m_doubles;
     L.ov_doubles = pick->off_nb;
@@ -1115,6 +1127,7 @@ int mtp_compute_device_rows(mtp_context *c, void *stream, int row_begin, int row
   p.dg_mode = L.layout.mode;
   p.pow_row = L.layout.pow_row;
   p.dg_off = L.layout.dg_off;
+  p.fp_row = L.layout.fp_row;
   p.w_m = L.layout.off_m;
   p.w_d = L.layout.off_d;
   p.w_coef = L.layout.off_coef;

@@ -90,9 +90,10 @@ struct MtpDevParams {
   int NT;                  // neighbours per LDS tile: 32 (table row pitch MTP_PITCH doubles)
   int tab_rows;            // table rows = 2*nslot + 3*P (candidate-vector kernel: 4*P + R)
   // per-atom LDS image (mtp_kernels.hip, WaveLds): offsets in doubles from the start of the wavefront's region
-  int dg_mode;             // 0 "keep": dg rows written by the tile build; 1 "lean": written ahead of the force phase from
-                           // radial derivatives parked in registers; 2 "rebuild": g and dg rows built a second time
-  int rebuild_tables;      // dg_mode == 2 (kept for the launch-info report)
+  int dg_mode;             // bit 0 "nodg": no dg rows -- Mu rows f'_mu written ahead of the force phase from radial derivatives
+                           // parked in registers (Mu <= 4); bit 1 "rebuild": g (and dg) rows built a second time
+  int fp_row;              // nodg: table row of f'_0 (rows fp_row .. fp_row + Mu - 1), behind the coefficient blocks
+  int rebuild_tables;      // dg_mode & 2 (kept for the launch-info report)
   int pow_row;             // first coordinate-power row of the table: 2*nslot (keep) or nslot
   int dg_off;              // from a g row to its dg row
   int w_m, w_d, w_coef, w_nb;   // moments, adjoints, derivative-polynomial coefficients, neighbour arrays

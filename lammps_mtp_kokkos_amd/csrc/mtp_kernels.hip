@@ -71,18 +71,21 @@ template <int PITCH> struct WaveLds {
   __device__ __forceinline__ unsigned addr(const double *ptr) const { return m_addr + 8u * (unsigned) (ptr - M); }
   __device__ __forceinline__ WaveLds(double *base, unsigned base_addr, KP kp)
   {
-    // Three layouts of the per-atom image, chosen by the host planner (mtp_context.hip, plan()); all of them are
-    // [tables | overlay | neighbour arrays] with the regions placed through offsets in the parameter block:
+    // Layouts of the per-atom image, chosen by the host planner (mtp_context.hip, plan()); all of them are
+    // [tables | overlay | neighbour arrays] with the regions placed through offsets in the parameter block
+    // (dg_mode: bit 0 = no dg rows, bit 1 = rebuild):
     //   keep     [g rows | dg rows | overlay]: the coordinate-power rows live in the overlay from the tile build to the
     //            end of the basic-moment pass, the moments / adjoints (later the derivative-polynomial coefficients)
     //            from there on -- the two are never live together;
-    //   lean     [g rows | overlay]: the dg rows join the overlay (behind the coefficient blocks): the tile build keeps
-    //            the radial derivatives f'_mu(r) of its neighbour in registers and the dg rows are written from them
-    //            ahead of the force phase (no second evaluation of the radial functions);
+    //   nodg     [g rows | overlay] (Mu <= 4): no dg rows.  d/dr (f_mu / r^nu) = f'_mu / r^nu - nu g / r, so
+    //            sum_s (dg_s / nu) G_s = sum_s f'_mu(s) (r^-nu / nu) G_s - (1/r) sum_s g_s G_s: the tile build parks the
+    //            radial derivatives f'_mu(r) of its neighbour in registers, Mu rows of them (instead of one dg row per
+    //            slot) are written behind the coefficient blocks ahead of the force phase, which multiplies them in
+    //            per slot and subtracts the g sums it forms anyway;
     //   rebuild  everything overlays everything (potentials with many moments): the moments and adjoints sit on the
-    //            g rows, which are built a second time, with the dg rows, ahead of the force phase (the coefficient
-    //            blocks sit behind the rows, the adjoints of the basics D[0, B) in front: the host checks that they
-    //            cannot meet).
+    //            g rows, which are built a second time (with the dg rows unless nodg) ahead of the force phase (the
+    //            coefficient blocks sit behind the rows, the adjoints of the basics D[0, B) in front: the host checks
+    //            that they cannot meet).
     tab = base;
     M = tab + kp->w_m;
     D = tab + kp->w_d;
@@ -101,8 +104,8 @@ template <int PITCH> struct WaveLds {
 
 // Phase 2: tables of one tile; columns [0, ntp) are written, ntp = nt rounded up to the
 // neighbour-group count with dummy neighbours sitting exactly on the cutoff (g = dg = 0).
-// with_dg: write the dg rows; do_park (lean layout): park[] receives f'_mu(r) of this lane's neighbour for its radial
-// functions mu = h, h + 2, h + 4 (park[0..2]), from which dg_from_parked() writes the dg rows later.
+// with_dg: write the dg rows; do_park (nodg layouts): park[] receives f'_mu(r) of this lane's neighbour for its radial
+// functions mu = h, h + 2 (park[0..1]), from which fp_from_parked() writes the f' rows ahead of the force phase.
 #define MTP_PARK 2   // radial functions per half-wavefront that can be parked: Mu <= 4
 template <int PITCH>
 __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const WaveLds<PITCH> &w,
@@ -252,34 +255,18 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
   wave_fence();
 }
 
-// Lean layout, ahead of the force phase: dg rows of the (single) tile from the parked radial derivatives and the g rows
-// that stayed in LDS: d/dr (f_mu / r^nu) = f'_mu / r^nu - nu (f_mu / r^nu) / r, the expression of build_tile().
+// nodg layouts, ahead of the force phase: the Mu rows f'_mu(r_n) of the tile from the derivatives the tile build parked
+// in registers (row fp_row + mu; two stores per lane instead of one dg row per slot)
 template <int PITCH>
-__device__ __forceinline__ void dg_from_parked(KP kp, const BlockTables &bt, const WaveLds<PITCH> &w, int ntp,
-                                               const double (&park)[MTP_PARK], int lane)
+__device__ __forceinline__ void fp_from_parked(KP kp, const WaveLds<PITCH> &w, int ntp, const double (&park)[MTP_PARK], int lane)
 {
-  const int n = lane & 31, h = lane >> 5, Mu = kp->Mu, P = kp->P;
+  const int n = lane & 31, h = lane >> 5, Mu = kp->Mu;
   if (n < ntp) {
-    const double inv = w.nbi[n];
-    double *col = w.tab + n;
+    double *col = w.tab + n + (size_t) kp->fp_row * PITCH;
 #pragma unroll
     for (int mi = 0; mi < MTP_PARK; mi++) {
       const int mu = 2 * mi + h;
-      if (mu < Mu) {
-        const int4 *sl4 = reinterpret_cast<const int4 *>(bt.slot + mu * MTP_PSTRIDE);
-        const int4 sa = sl4[0], sb = sl4[1], sc = sl4[2];
-        const int sv[MTP_PSTRIDE] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w, sc.x, sc.y, sc.z, sc.w};
-        const double der = park[mi];
-        double rp = 1.0;
-#pragma unroll
-        for (int nu = 0; nu < MTP_PSTRIDE; nu++) {
-          if (nu < P) {
-            const int sidx = sv[nu];
-            if (sidx >= 0) col[kp->dg_off + sidx * PITCH] = der * rp - nu * col[sidx * PITCH] * inv;
-            rp *= inv;
-          }
-        }
-      }
+      if (mu < Mu) col[mu * PITCH] = park[mi];
     }
   }
   wave_fence();
@@ -566,9 +553,12 @@ template <int C> __device__ __forceinline__ double poly_eval(unsigned coef, cons
 // (a descending, then b descending): idx(a, b, c) = j (j + 1) / 2 + c with j = b + c.  A slot's coefficient
 // block is [d/dx | d/dy | d/dz], each over those monomials.  UA/VA collect sum_s g_s dP_s/dx (half 0) or
 // dP_s/dz (half 1) and the same with dg_s / nu; UB/VB the d/dy terms of the slots this half owns.
+// NODG: no dg rows -- VA / VB collect sum_s f'_mu(s) (r^-nu / nu) G_s instead (f'_mu(r) of this lane's neighbour from
+// row fp_row + mu of the tile, rw = r^-NU on entry) and the caller subtracts (UA, UB) / r at the end:
+// dg_s = f'_mu r^-nu - nu g_s / r.
 // GRADE (fused candidate vectors): W[mu] collects this lane's share of W_mu(n) = sum_{s in mu} P_s(r_n) / r_n^nu
-// (pair_mtp_extrapolation.cpp:193-198), again through P_s = (r . grad P_s) / nu; rw = r^-NU on entry.
-template <int NU, int DEG, int PITCH, bool GRADE>
+// (pair_mtp_extrapolation.cpp:193-198), again through P_s = (r . grad P_s) / nu.
+template <int NU, int DEG, int PITCH, bool GRADE, bool NODG>
 __device__ __forceinline__ void force_degree(KP kp, unsigned pcol, unsigned pcoef, int part, double x,
                                              double y, double z, double *m, double &UA, double &VA, double &UB,
                                              double &VB, const int *smu, double inv, double rw, double *W)
@@ -579,17 +569,21 @@ __device__ __forceinline__ void force_degree(KP kp, unsigned pcol, unsigned pcoe
       const int s0 = kp->deg_first[NU], cnt = kp->deg_first[NU + 1] - s0;
       const double inv_nu = 1.0 / NU;
       const unsigned dgo = 8u * (unsigned) kp->dg_off;
-      const double wa = GRADE ? (part ? z : x) * (rw * inv_nu) : 0.0, wb = GRADE ? y * (rw * inv_nu) : 0.0;
+      const unsigned pfp = pcol + 8u * (unsigned) (kp->fp_row * PITCH);   // f' rows of this lane's column (NODG)
+      const double rwn = rw * inv_nu;
+      const double wa = GRADE ? (part ? z : x) * rwn : 0.0, wb = GRADE ? y * rwn : 0.0;
       {
         unsigned ca = pcoef + 8u * (unsigned) (kp->deg_coef[NU] + part * 2 * C);
         unsigned cg = pcol + 8u * (unsigned) (s0 * PITCH);
         for (int it = 0; it < cnt; it++) {
-          const double g = lds_ld(cg, 0), dg = lds_ld(cg + dgo, 0);
+          // the slot, hence mu, is wave-uniform in this pass
+          const int mu = (NODG || GRADE) ? __builtin_amdgcn_readfirstlane(smu[s0 + it]) : 0;
+          const double g = lds_ld(cg, 0);
+          const double dg = NODG ? lds_ld(pfp + 8u * (unsigned) (mu * PITCH), 0) : lds_ld(cg + dgo, 0);   // NODG: f'_mu
           const double G = poly_eval<C>(ca, m);
           UA = fma(g, G, UA);
-          VA = fma(dg * inv_nu, G, VA);
-          if (GRADE) {   // the slot, hence mu, is wave-uniform in this pass: scalar branches, one add
-            const int mu = __builtin_amdgcn_readfirstlane(smu[s0 + it]);
+          VA = fma(dg * (NODG ? rwn : inv_nu), G, VA);
+          if (GRADE) {
             const double val = G * wa;
             if (mu == 0) W[0] += val;
             else if (mu == 1) W[1] += val;
@@ -606,13 +600,16 @@ __device__ __forceinline__ void force_degree(KP kp, unsigned pcol, unsigned pcoe
         const int sc = ok ? si : 0;
         const unsigned cb = pcoef + 8u * (unsigned) (kp->deg_coef[NU] + sc * 3 * C + C);
         const unsigned cg = pcol + 8u * (unsigned) ((s0 + sc) * PITCH);
-        const double g_raw = lds_ld(cg, 0), dg_raw = lds_ld(cg + dgo, 0);
+        // (the halves hold different slots, hence different mu: a per-lane value here)
+        const int mu_raw = (NODG || GRADE) ? smu[s0 + sc] : 0;
+        const double g_raw = lds_ld(cg, 0);
+        const double dg_raw = NODG ? lds_ld(pfp + 8u * (unsigned) (mu_raw * PITCH), 0) : lds_ld(cg + dgo, 0);
         const double G = poly_eval<C>(cb, m);
         const double g = ok ? g_raw : 0.0, dg = ok ? dg_raw : 0.0;
         UB = fma(g, G, UB);
-        VB = fma(dg * inv_nu, G, VB);
+        VB = fma(dg * (NODG ? rwn : inv_nu), G, VB);
+        const int mu = ok ? mu_raw : -1;
         if (GRADE) {
-          const int mu = ok ? smu[s0 + sc] : -1;
           const double val = G * wb;
 #pragma unroll
           for (int v = 0; v < 4; v++) W[v] += mu == v ? val : 0.0;
@@ -626,7 +623,7 @@ __device__ __forceinline__ void force_degree(KP kp, unsigned pcol, unsigned pcoe
         m[C + NU] = z * m[T0 + NU - 1];
 #pragma unroll
         for (int i = 0; i < C; i++) m[i] *= x;
-        force_degree<NU + 1, DEG, PITCH, GRADE>(kp, pcol, pcoef, part, x, y, z, m, UA, VA, UB, VB, smu, inv, rw * inv, W);
+        force_degree<NU + 1, DEG, PITCH, GRADE, NODG>(kp, pcol, pcoef, part, x, y, z, m, UA, VA, UB, VB, smu, inv, rw * inv, W);
       }
     }
   }
@@ -642,6 +639,9 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
   // way) run the gather programs -- measured at level 20: 2.02 -> 1.93 ms; the narrow grids keep the row-per-lane passes
   // with the rows in LDS -- at level 16 the gather programs (27 KB, so in L2) were 2.3 % slower (0.523 vs 0.511 ms).
   constexpr bool GATHER = KL == 64;
+  // The 3-per-SIMD build is planned with the dg-free layouts only (its table shapes have Mu <= 4), so the dg paths are
+  // compiled out of it; the 2-per-SIMD build takes either (uniform flag).
+  constexpr bool NODG_CT = WPS == 3;
   constexpr int NG = 64 / KL;            // neighbour groups in the wavefront
   constexpr int NPG = NT / NG;           // neighbours per group per tile
   static_assert(NT == 32, "the force phase maps lanes to (32 neighbours) x (2 halves)");
@@ -849,11 +849,11 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       block_addresses(kl_o);
     }
     const int ntiles = (cnt + NT - 1) / NT;
-    double park[MTP_PARK] = {0.0, 0.0};   // lean layout: f'_mu(r) of this lane's neighbour (single-tile atoms)
+    const bool nodg = NODG_CT || (kp->dg_mode & 1) != 0, rebuild = (kp->dg_mode & 2) != 0;
+    double park[MTP_PARK] = {0.0, 0.0};   // nodg layouts: f'_mu(r) of this lane's neighbour, mu = half, half + 2
     for (int tile = 0; tile < ntiles; tile++) {
       const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-      build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, tile > 0, true, kp->dg_mode == 0, kp->dg_mode == 1, park, xi0, xi1, xi2, i,
-                        itype, lane);
+      build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, tile > 0, true, !nodg && !rebuild, nodg, park, xi0, xi1, xi2, i, itype, lane);
       STAMP(2);   // tile tables
 #pragma unroll
       for (int m = 0; m < NPG; m++) {
@@ -1007,31 +1007,36 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       double crad = 0.0;
       for (int tile = 0; tile < ntiles; tile++) {
         const int t0 = tile * NT, nt = min(NT, cnt - t0), ntp = ((nt + NG - 1) / NG) * NG;
-        if (ntiles > 1 || kp->dg_mode == 2)
-          build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, ntiles > 1, false, true, false, park, xi0, xi1, xi2, i, itype, lane);
-        else if (kp->dg_mode == 1)
-          dg_from_parked<PITCH>(kp, bt, w, ntp, park, lane);
+        if (ntiles > 1 || rebuild)   // (single-tile atoms in the persistent layouts: the g rows and park[] of the tile build stand)
+          build_tile<PITCH>(kp, bt, w, t0, cnt, ntp, ntiles > 1, false, !nodg, nodg, park, xi0, xi1, xi2, i, itype, lane);
+        if (nodg) fp_from_parked<PITCH>(kp, w, ntp, park, lane);
         // columns past ntp hold stale (finite or not) data: their lanes are masked at the end
         const double x = w.nbx[n], y = w.nby[n], z = w.nbz[n], inv = w.nbi[n];
         double UA = 0.0, VA = 0.0, UB = 0.0, VB = 0.0, S0 = 0.0;
         double Wm[4] = {0.0, 0.0, 0.0, 0.0};
         const bool fused = GRADE && kp->grade_fused;
-        {   // rank 0: P_s = D_k, no gradient
-          unsigned cg = pcol + 8u * (unsigned) kp->dg_off;
+        {   // rank 0: P_s = D_k, no gradient; dg_s = f'_mu (nodg: its row fp_row + mu; else the slot's dg row)
+          const unsigned cg0 = pcol + 8u * (unsigned) (nodg ? kp->fp_row * PITCH : kp->dg_off);
           for (int sidx = 0; sidx < kp->deg_first[1]; sidx++) {
             const double dk = w.coef[kp->deg_coef[0] + sidx];
-            S0 = fma(lds_ld(cg, 0), dk, S0);
+            const int mu = (nodg || GRADE) ? __builtin_amdgcn_readfirstlane(bt.smu[sidx]) : 0;
+            S0 = fma(lds_ld(cg0 + 8u * (unsigned) ((nodg ? mu : sidx) * PITCH), 0), dk, S0);
             if (GRADE) {
-              const int mu = bt.smu[sidx];
 #pragma unroll
               for (int v = 0; v < 4; v++) Wm[v] += (mu == v && part == 0) ? dk : 0.0;
             }
-            cg += 8u * PITCH;
           }
         }
         double mono[DEG * (DEG + 1) / 2];
         mono[0] = 1.0;
-        force_degree<1, DEG, PITCH, GRADE>(kp, pcol, w.addr(w.coef), part, x, y, z, mono, UA, VA, UB, VB, bt.smu, inv, inv, Wm);
+        if (nodg) {
+          force_degree<1, DEG, PITCH, GRADE, true>(kp, pcol, w.addr(w.coef), part, x, y, z, mono, UA, VA, UB, VB, bt.smu, inv, inv, Wm);
+          // dg_s / nu = f'_mu r^-nu / nu - g_s / r: the second term of every slot at once
+          VA = fma(-inv, UA, VA);
+          VB = fma(-inv, UB, VB);
+        } else if constexpr (!NODG_CT) {
+          force_degree<1, DEG, PITCH, GRADE, false>(kp, pcol, w.addr(w.coef), part, x, y, z, mono, UA, VA, UB, VB, bt.smu, inv, inv, Wm);
+        }
         if (fused) {
           // c[jt][mu][ri] += sum_n [type_n = jt] Q_ri(r_n) W_mu(n)  (pair_mtp_extrapolation.cpp:193-198, 323-329):
           // half h of the wavefront reduces the 32 (mu, ri) entries of jt = h over its 32 neighbour lanes
