@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of tuning knobs on the headline workload, each configuration timed ROUNDS times in alternation (box clocks drift):
 #   bash scripts/gpu_ab.sh TAG "ENV1=a ENV2=b" "ENV1=c" ...      ("-" = defaults; VARIANTS="name:-DFLAG ..." builds
-#   diagnostic libraries libmtp_mi355x_<name>.so first, selectable with MTP_LIB=lammps_mtp_kokkos_amd/libmtp_mi355x_<name>.so)
+#   diagnostic libraries ab/libmtp_mi355x_<name>.so first, selectable with MTP_LIB=lammps_mtp_kokkos_amd/ab/libmtp_mi355x_<name>.so)
 set -o pipefail
 TAG=${1:-ab}; shift
 OUT=gpurun_out/$TAG

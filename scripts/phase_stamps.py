@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase share of wave cycles from the stamped build (make -C csrc stamps).
-Run with MTP_LIB=lammps_mtp_kokkos_amd/libmtp_mi355x_stamps.so on the GPU box."""
+Run with MTP_LIB=lammps_mtp_kokkos_amd/ab/libmtp_mi355x_stamps.so on the GPU box."""
 import ctypes as C
 import os
 import sys
