@@ -458,8 +458,8 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     hipStream_t st = c->stream;
     c->d_species.upload(pot->species_coeffs, st);
     // packed rows (8 B each): moment ids in 16 bits, multiplicity in a signed 16 bits
-    if (pot->alpha_moment_count > 65535) {
-      copy_err("alpha_moments_count above 65535 is not supported by this build", err, errlen);
+    if (pot->alpha_moment_count > 8191) {   // (packed rows hold 16-bit byte offsets; 8192 moments are 128 KB of LDS anyway)
+      copy_err("alpha_moments_count above 8191 is not supported by this build", err, errlen);
       delete c;
       return MTP_ERR_LIMIT;
     }
@@ -471,16 +471,16 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
         delete c;
         return MTP_ERR_LIMIT;
       }
-      rows8[k].lo = (uint32_t) r.a0 | ((uint32_t) r.a1 << 16);
-      rows8[k].hi = (uint32_t) r.a3 | (((uint32_t) r.mult & 0xffffu) << 16);
+      rows8[k].lo = (uint32_t) (8 * r.a0) | ((uint32_t) (8 * r.a1) << 16);
+      rows8[k].hi = (uint32_t) (8 * r.a3) | (((uint32_t) r.mult & 0xffffu) << 16);
     }
     c->d_rows.upload(rows8.data(), rows8.size(), st);
     auto pack_prog = [&](const std::vector<MtpRow> &prog, DevBuf<MtpRow8> &buf) {
       std::vector<MtpRow8> p8(prog.size());
       for (size_t k = 0; k < prog.size(); k++) {
         const MtpRow &r = prog[k];
-        p8[k].lo = (uint32_t) r.a0 | ((uint32_t) r.a1 << 16);
-        p8[k].hi = (uint32_t) r.a3 | (((uint32_t) r.mult & 0xffffu) << 16);
+        p8[k].lo = (uint32_t) (8 * r.a0) | ((uint32_t) (8 * r.a1) << 16);
+        p8[k].hi = (uint32_t) (8 * r.a3) | (((uint32_t) r.mult & 0xffffu) << 16);
       }
       buf.upload(p8.data(), p8.size(), st);
     };
@@ -608,6 +608,7 @@ int mtp_context_create(const mtp_potential *pot, int device_id, mtp_context **ou
     b.scaling = pot->scaling;
     b.cutsq = pot->max_cutoff * pot->max_cutoff;   // pair_mtp.cpp:449,456
     b.inv_span = 1.0 / (pot->max_cutoff - pot->min_cutoff);
+    b.inv_rmax = 1.0 / pot->max_cutoff;
     b.blob = c->d_blob.ptr;
     b.rows = c->d_rows.ptr;
     b.prog_fwd = c->d_prog_fwd.ptr;

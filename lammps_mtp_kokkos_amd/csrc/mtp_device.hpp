@@ -12,7 +12,8 @@
 #define MTP_PITCH 33        // doubles per row of the per-wavefront LDS tables (32 neighbour columns + 1: odd pitch)
 #define MTP_PSTRIDE 12      // slot ids per mu in the LDS blob (nu = 0..11, -1 padded)
 
-// A times row packed in 8 bytes: lo = a0 | a1 << 16, hi = a3 | (mult & 0xffff) << 16
+// A times row packed in 8 bytes: lo = 8 a0 | 8 a1 << 16, hi = 8 a3 | (mult & 0xffff) << 16 -- BYTE offsets of the moments
+// in the per-atom LDS image (moment indices below 8192)
 struct alignas(8) MtpRow8 {   // 8-byte aligned: one ds_read_b64 / global_load_dwordx2 per row, not two dword reads
   uint32_t lo, hi;
 };
@@ -35,6 +36,7 @@ struct MtpDevParams {
   int coef_total;          // doubles of all coefficient blocks
   int coef_dense;          // every coefficient has a source basic (no zero fill)
   double rmin, rmax, scaling, cutsq, inv_span;   // inv_span = 1 / (rmax - rmin)
+  double inv_rmax;
   // Read-mostly tables, one contiguous blob in HBM that every workgroup copies into the
   // head of its LDS once; offsets in bytes from the blob start (all 8-byte aligned).
   const unsigned char *blob;

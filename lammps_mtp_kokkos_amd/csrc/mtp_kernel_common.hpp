@@ -30,6 +30,23 @@ static __device__ __forceinline__ void wave_fence()
   __builtin_amdgcn_wave_barrier();
 }
 
+// r = sqrt(r2) and inv = 1 / r from ONE v_rsq_f64 (r2 > 0, normal range: squared interatomic distances): two
+// Newton steps on y ~ r2^-1/2 (relative error 2^-26 -> 2^-52 -> rounding), then r = r2 y with one correction step.
+// Both results are within 1 ulp of the correctly rounded values the reference's std::sqrt and division give
+// (pair_mtp.cpp:128-129) -- 1e-16 relative, seven orders inside the parity tolerance -- at 11 instead of 24 VALU
+// instructions (sqrt expansion + division expansion).
+static __device__ __forceinline__ void sqrt_and_inverse(double r2, double &r, double &inv)
+{
+  double y = __builtin_amdgcn_rsq(r2);
+  const double h = 0.5 * r2;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  double s = r2 * y;
+  s = fma(fma(-s, s, r2), 0.5 * y, s);
+  r = s;
+  inv = y;
+}
+
 static __device__ __forceinline__ double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
 
 static __device__ __forceinline__ double uniform_f64(double v)   // v is wave-uniform: move it to SGPRs
@@ -147,6 +164,22 @@ template <int N> struct Butterfly {
 template <> struct Butterfly<1> {
   static __device__ __forceinline__ void run(double *, int) {}
 };
+
+// The same for NINE entries v[0..8] over the lane bits below 16 (the force totals: 3 force and 6 virial components):
+// entry 8 pairs with entry 0 in the first step; entries 1..7 have no partner entry there, so that step is a plain
+// pair sum for them (3 instead of 7 instructions each).  On exit v[0] of lane l holds entry l for l & 15 in 0..8.
+static __device__ __forceinline__ void butterfly9(double *v, int lane)
+{
+  const bool hi = (lane & 8) != 0;
+  {
+    const double keep = hi ? v[8] : v[0];
+    const double send = hi ? v[0] : v[8];
+    v[0] = keep + partner_f64<8>(send, lane);
+  }
+#pragma unroll
+  for (int i = 1; i < 8; i++) v[i] += partner_f64<8>(v[i], lane);
+  Butterfly<8>::run(v, lane);
+}
 
 struct BlockTables {   // views into the workgroup-shared head of LDS
   const MtpRow8 *rows;

@@ -117,18 +117,18 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
     if (lane < ntp) {
       const bool real = t0 + lane < cnt;
       const int j = real ? w.cj[t0 + lane] : i;
-      double dx = 0, dy = 0, dz = 0, r = kp->rmax;
+      double dx = 0, dy = 0, dz = 0, r = kp->rmax, inv = kp->inv_rmax;
       if (real) {
         dx = kp->x[3 * (size_t) j] - xi0;
         dy = kp->x[3 * (size_t) j + 1] - xi1;
         dz = kp->x[3 * (size_t) j + 2] - xi2;
-        r = sqrt(dx * dx + dy * dy + dz * dz);
+        sqrt_and_inverse(dx * dx + dy * dy + dz * dz, r, inv);
       }
       w.nbx[lane] = dx;
       w.nby[lane] = dy;
       w.nbz[lane] = dz;
       w.nbr[lane] = r;
-      w.nbi[lane] = 1.0 / r;
+      w.nbi[lane] = inv;
       w.nbj[lane] = j;
       w.nbjt[lane] = real ? kp->type[j] - 1 : itype;
     }
@@ -272,6 +272,17 @@ __device__ __forceinline__ void fp_from_parked(KP kp, const WaveLds<PITCH> &w, i
   wave_fence();
 }
 
+// Packed rows carry BYTE offsets (8 x moment index) in their 16-bit fields, so that an LDS address is one
+// v_add_u32_sdwa (base + 16-bit word of the row) instead of a bit-field extract and a shift-add.
+static __device__ __forceinline__ double &at8(double *base, unsigned byte_off)
+{
+  return *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byte_off);
+}
+static __device__ __forceinline__ const double &at8(const double *base, unsigned byte_off)
+{
+  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
 // Phase 4a: M[a3] += mult * M[a0] * M[a1], one dependency level at a time.  Rows of one level
 // never write an operand of the same level, so four rows per lane are in flight before their
 // ds_add_f64 issue.  (Two call sites, LDS-resident and HBM-resident rows: a select between the two
@@ -291,10 +302,10 @@ __device__ __forceinline__ void products_forward(const MtpRow8 *rows, const int 
 #pragma unroll
       for (int u = 0; u < U; u++) rw[u] = rp[64 * min(it + u, nit - 1)];   // uniform clamp: the tail re-reads the last block
 #pragma unroll
-      for (int u = 0; u < U; u++) v[u] = M[rw[u].lo & 0xffffu] * M[rw[u].lo >> 16];
+      for (int u = 0; u < U; u++) v[u] = at8(M, rw[u].lo & 0xffffu) * at8(M, rw[u].lo >> 16);
 #pragma unroll
       for (int u = 0; u < U; u++)
-        if (it + u < nit) lds_add(&M[rw[u].hi & 0xffffu], (double) ((int) rw[u].hi >> 16) * v[u]);   // uniform branch
+        if (it + u < nit) lds_add(&at8(M, rw[u].hi & 0xffffu), (double) ((int) rw[u].hi >> 16) * v[u]);   // uniform branch
     }
     wave_fence();
   }
@@ -316,15 +327,15 @@ __device__ __forceinline__ void products_backward(const MtpRow8 *rows, const int
       for (int u = 0; u < U; u++) rw[u] = rp[64 * min(it + u, nit - 1)];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        d3[u] = D[rw[u].hi & 0xffffu] * (double) ((int) rw[u].hi >> 16);
-        m0[u] = M[rw[u].lo & 0xffffu];
-        m1[u] = M[rw[u].lo >> 16];
+        d3[u] = at8(D, rw[u].hi & 0xffffu) * (double) ((int) rw[u].hi >> 16);
+        m0[u] = at8(M, rw[u].lo & 0xffffu);
+        m1[u] = at8(M, rw[u].lo >> 16);
       }
 #pragma unroll
       for (int u = 0; u < U; u++)
         if (it + u < nit) {
-          lds_add(&D[rw[u].lo >> 16], d3[u] * m0[u]);
-          lds_add(&D[rw[u].lo & 0xffffu], d3[u] * m1[u]);
+          lds_add(&at8(D, rw[u].lo >> 16), d3[u] * m0[u]);
+          lds_add(&at8(D, rw[u].lo & 0xffffu), d3[u] * m1[u]);
         }
     }
     wave_fence();
@@ -382,12 +393,12 @@ __device__ __forceinline__ double leaf_forward(const MtpRow8 *rows, const double
           fetch(b, rw, c);
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) v[u] = M[rw[u].lo & 0xffffu] * M[rw[u].lo >> 16];
+        for (int u = 0; u < U; u++) v[u] = at8(M, rw[u].lo & 0xffffu) * at8(M, rw[u].lo >> 16);
 #pragma unroll
         for (int u = 0; u < U; u++)
           if (b * U + u < nit) {   // uniform branch
             e = fma(c[u], v[u], e);
-            if (STORE) lds_add(&M[rw[u].hi & 0xffffu], (double) ((int) rw[u].hi >> 16) * v[u]);
+            if (STORE) lds_add(&at8(M, rw[u].hi & 0xffffu), (double) ((int) rw[u].hi >> 16) * v[u]);
           }
       }
     }
@@ -438,14 +449,14 @@ __device__ __forceinline__ void leaf_backward(const MtpRow8 *rows, const double 
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          m0[u] = M[rw[u].lo & 0xffffu];
-          m1[u] = M[rw[u].lo >> 16];
+          m0[u] = at8(M, rw[u].lo & 0xffffu);
+          m1[u] = at8(M, rw[u].lo >> 16);
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
           if (b * U + u < nit) {
-            lds_add(&D_[rw[u].lo >> 16], c[u] * m0[u]);
-            lds_add(&D_[rw[u].lo & 0xffffu], c[u] * m1[u]);
+            lds_add(&at8(D_, rw[u].lo >> 16), c[u] * m0[u]);
+            lds_add(&at8(D_, rw[u].lo & 0xffffu), c[u] * m1[u]);
           }
       }
     }
@@ -490,8 +501,8 @@ __device__ __forceinline__ void gather_groups(const MtpRow8 *rp, int ngroups, co
     for (int j = 0; j < G; j++)
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        xv[j][u] = X[cur[j][u].lo & 0xffffu];
-        yv[j][u] = Y[cur[j][u].lo >> 16];
+        xv[j][u] = at8(X, cur[j][u].lo & 0xffffu);
+        yv[j][u] = at8(Y, cur[j][u].lo >> 16);
       }
 #pragma unroll
     for (int j = 0; j < G; j++)
@@ -501,7 +512,7 @@ __device__ __forceinline__ void gather_groups(const MtpRow8 *rp, int ngroups, co
       const int g0 = (trip / PARTS) * G;
 #pragma unroll
       for (int j = 0; j < G; j++) {
-        if (g0 + j < ngroups) lds_add(&T[cur[j][0].hi & 0xffffu], acc[j]);   // uniform branch
+        if (g0 + j < ngroups) lds_add(&at8(T, cur[j][0].hi & 0xffffu), acc[j]);   // uniform branch
         acc[j] = 0.0;
       }
     }
@@ -783,34 +794,33 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
         d2[u][1] = kp->x[3 * (size_t) j2[u] + 1];
         d2[u][2] = kp->x[3 * (size_t) j2[u] + 2];
       }
+      // (no branch on the loaded values ahead of the arithmetic: the compiler otherwise sinks the position loads of the
+      // first entry behind its type check -- one more dependent memory round trip per atom)
+      bool bad = false;
+#pragma unroll
+      for (int u = 0; u < 2; u++) bad = bad || (ok2[u] && (jt2[u] < 0 || jt2[u] >= kp->Sp));
+      if (__ballot(bad) != 0ull) {   // pair_mtp.cpp:116-118 (uniform, never taken with a valid type array)
+        if (bad) atomicExch(kp->err_flag, 1);
+      }
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         if (u == 1 && c0 + 64 >= jnum) break;   // uniform
         const int j = j2[u], jt = jt2[u];
-        bool in = false;
-        double dx = 0, dy = 0, dz = 0, r2 = 1.0;
-        if (ok2[u]) {
-          if (jt < 0 || jt >= kp->Sp) {   // pair_mtp.cpp:116-118
-            atomicExch(kp->err_flag, 1);
-          } else {
-            dx = d2[u][0] - xi0;
-            dy = d2[u][1] - xi1;
-            dz = d2[u][2] - xi2;
-            r2 = dx * dx + dy * dy + dz * dz;
-            in = !(r2 > kp->cutsq);   // pair_mtp.cpp:123
-          }
-        }
+        const double dx = d2[u][0] - xi0, dy = d2[u][1] - xi1, dz = d2[u][2] - xi2;
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        const bool in = ok2[u] && jt >= 0 && jt < kp->Sp && !(r2 > kp->cutsq);   // pair_mtp.cpp:123
         const unsigned long long m = __ballot(in);
         if (in) {
           const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
           w.cj[min(pos, cj_last)] = j;   // a list longer than the declared max_numneigh is reported below
           if (pos < NT) {
-            const double r = sqrt(r2);
+            double r, inv;
+            sqrt_and_inverse(r2, r, inv);
             w.nbx[pos] = dx;
             w.nby[pos] = dy;
             w.nbz[pos] = dz;
             w.nbr[pos] = r;
-            w.nbi[pos] = 1.0 / r;
+            w.nbi[pos] = inv;
             w.nbj[pos] = j;
             w.nbjt[pos] = jt;
           }
@@ -829,7 +839,7 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
         w.nby[pos] = 0.0;
         w.nbz[pos] = 0.0;
         w.nbr[pos] = kp->rmax;
-        w.nbi[pos] = 1.0 / kp->rmax;
+        w.nbi[pos] = kp->inv_rmax;
         w.nbj[pos] = i;
         w.nbjt[pos] = itype;
       }
@@ -1097,9 +1107,9 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
           vacc[5] += v5;
         }
         if (v_per_atom) {
-          double part16[16] = {Fx, Fy, Fz, v0, v1, v2, v3, v4, v5, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-          Butterfly<16>::run(part16, lane);
-          tot = part16[0];
+          double part9[9] = {Fx, Fy, Fz, v0, v1, v2, v3, v4, v5};
+          butterfly9(part9, lane);
+          tot = part9[0];
         } else {
           // the mirror partners flip the low lane bits too, so they go first (while every lane still holds
           // all entries); the quad butterfly then leaves entry (lane & 3) summed over the row
