@@ -760,17 +760,27 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     ii_end = kp->row0 + kp->inum;
   }
   for (int ii = ii_beg; ii < ii_end; ii += ii_step) {
-    // ii is wave-uniform, so is everything loaded through it: keep it in SGPRs
-    const int i = __builtin_amdgcn_readfirstlane(kp->ilist[ii]);
-    const int itype = __builtin_amdgcn_readfirstlane(kp->type[i] - 1);
+    // ii is wave-uniform, so is everything loaded through it: keep it in SGPRs.  Three dependent memory round trips
+    // per atom: {ilist, first} -> {type_i, x_i, the row's first 128 neighbour ids} -> {x_j, type_j}: every load of a
+    // stage is requested before the first wait, and before the type check branches.
+    const int i_raw = kp->ilist[ii], jbeg_raw = kp->first[ii], jend_raw = kp->first[ii + 1];
+    const int i = __builtin_amdgcn_readfirstlane(i_raw);
+    const int jbeg = __builtin_amdgcn_readfirstlane(jbeg_raw);
+    const int jnum = __builtin_amdgcn_readfirstlane(jend_raw) - jbeg;
+    int jpre[2] = {0, 0};   // neighbour ids of the first chunk
+    if (jnum > 0) {         // (uniform)
+#pragma unroll
+      for (int u = 0; u < 2; u++) jpre[u] = kp->neigh[jbeg + min(64 * u + lane, jnum - 1)];
+    }
+    const int itype_raw = kp->type[i];
+    const double x0_raw = kp->x[3 * (size_t) i], x1_raw = kp->x[3 * (size_t) i + 1], x2_raw = kp->x[3 * (size_t) i + 2];
+    asm volatile("" : "+v"(jpre[0]), "+v"(jpre[1]));   // (pins the first use of the ids behind the requests above)
+    const int itype = __builtin_amdgcn_readfirstlane(itype_raw) - 1;
+    const double xi0 = uniform_f64(x0_raw), xi1 = uniform_f64(x1_raw), xi2 = uniform_f64(x2_raw);
     if (itype < 0 || itype >= kp->Sp) {   // pair_mtp.cpp:91-93
       if (lane == 0) atomicExch(kp->err_flag, 1);
       continue;
     }
-    const double xi0 = uniform_f64(kp->x[3 * (size_t) i]), xi1 = uniform_f64(kp->x[3 * (size_t) i + 1]),
-                 xi2 = uniform_f64(kp->x[3 * (size_t) i + 2]);
-    const int jbeg = __builtin_amdgcn_readfirstlane(kp->first[ii]);
-    const int jnum = __builtin_amdgcn_readfirstlane(kp->first[ii + 1]) - jbeg;
 
     STAMP(0);   // loop head: ilist/type/x/first loads issue
     // ---- 1. compaction (the first NT survivors go straight into the tile arrays) --------
@@ -785,7 +795,7 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       for (int u = 0; u < 2; u++) {
         const int jj = c0 + 64 * u + lane;
         ok2[u] = jj < jnum;
-        j2[u] = kp->neigh[jbeg + min(jj, jnum - 1)] & MTP_NEIGHMASK;
+        j2[u] = (c0 == 0 ? jpre[u] : kp->neigh[jbeg + min(jj, jnum - 1)]) & MTP_NEIGHMASK;   // (uniform select)
       }
 #pragma unroll
       for (int u = 0; u < 2; u++) {
