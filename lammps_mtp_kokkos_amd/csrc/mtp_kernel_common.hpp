@@ -49,6 +49,18 @@ static __device__ __forceinline__ void sqrt_and_inverse(double r2, double &r, do
 
 static __device__ __forceinline__ double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
 
+// a * b for per-lane operands below 2^23 (table rows, slots, byte offsets inside one LDS image): v_mul_i32_i24 /
+// v_mad_i32_i24 issue at full rate, the 32- and 64-bit integer multiplies (v_mul_lo_u32, v_mad_u64_u32) at a quarter
+static __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+// &base[3 j] for an [n][3] double array: 24 j as shift-adds in 32 bits (j < 2^27 atoms), added as an unsigned offset
+static __device__ __forceinline__ const double *row3(const double *base, int j)
+{
+  unsigned j2 = (unsigned) j << 1;
+  asm volatile("" : "+v"(j2));   // (keeps the optimiser from folding the shift-adds back into a quarter-rate v_mul_lo_u32)
+  const unsigned j3 = j2 + (unsigned) j;
+  return reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (size_t) (j3 << 3));
+}
+
 static __device__ __forceinline__ double uniform_f64(double v)   // v is wave-uniform: move it to SGPRs
 {
   const long long b = __double_as_longlong(v);

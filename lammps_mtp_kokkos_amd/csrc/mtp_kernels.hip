@@ -119,9 +119,10 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
       const int j = real ? w.cj[t0 + lane] : i;
       double dx = 0, dy = 0, dz = 0, r = kp->rmax, inv = kp->inv_rmax;
       if (real) {
-        dx = kp->x[3 * (size_t) j] - xi0;
-        dy = kp->x[3 * (size_t) j + 1] - xi1;
-        dz = kp->x[3 * (size_t) j + 2] - xi2;
+        const double *xj = row3(kp->x, j);
+        dx = xj[0] - xi0;
+        dy = xj[1] - xi1;
+        dz = xj[2] - xi2;
         sqrt_and_inverse(dx * dx + dy * dy + dz * dz, r, inv);
       }
       w.nbx[lane] = dx;
@@ -173,7 +174,7 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
         const int4 *sl4 = reinterpret_cast<const int4 *>(bt.slot + mu * MTP_PSTRIDE);
         const int4 sa = sl4[0], sb = sl4[1], sc = sl4[2];
         const int sv[MTP_PSTRIDE] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w, sc.x, sc.y, sc.z, sc.w};
-        const double2 *c2 = reinterpret_cast<const double2 *>(bt.radial + ((itype * kp->Sp + jt) * Mu + mu) * 8);
+        const double2 *c2 = reinterpret_cast<const double2 *>(bt.radial + (mul24(itype * kp->Sp + jt, Mu) + mu) * 8);
         const double2 c01 = c2[0], c23 = c2[1], c45 = c2[2], c67 = c2[3];
         const double cc[8] = {c01.x, c01.y, c23.x, c23.y, c45.x, c45.y, c67.x, c67.y};
         double val = cc[0] * qv[0], der = cc[0] * ev[0];
@@ -189,8 +190,9 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
             const int sidx = sv[nu];
             const double g = val * rp;
             if (sidx >= 0) {
-              col[sidx * PITCH] = g;                                       // f_mu / r^nu
-              if (with_dg) col[kp->dg_off + sidx * PITCH] = der * rp - nu * g * inv;     // d/dr (f_mu / r^nu)
+              double *gp = col + mul24(sidx, PITCH);
+              *gp = g;                                                       // f_mu / r^nu
+              if (with_dg) gp[kp->dg_off] = der * rp - nu * g * inv;         // d/dr (f_mu / r^nu)
             }
             rp *= inv;
           }
@@ -200,7 +202,7 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
     } else {
       each_mu([&](int mu) {
         const int *sl = bt.slot + mu * MTP_PSTRIDE;
-        const double *c = bt.radial + ((itype * kp->Sp + jt) * Mu + mu) * R;
+        const double *c = bt.radial + mul24(mul24(itype * kp->Sp + jt, Mu) + mu, R);
         double q0 = kp->scaling * (d * d), q1 = kp->scaling * (ksi * d * d);
         double e0 = kp->scaling * 2.0 * d, e1 = kp->scaling * (mult * d * d + 2.0 * ksi * d);
         double val = c[0] * q0, der = c[0] * e0;
@@ -223,8 +225,9 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
           const int sidx = sl[nu];
           const double g = val * rp;
           if (sidx >= 0) {
-            col[sidx * PITCH] = g;
-            if (with_dg) col[kp->dg_off + sidx * PITCH] = der * rp - nu * g * inv;
+            double *gp = col + mul24(sidx, PITCH);
+            *gp = g;
+            if (with_dg) gp[kp->dg_off] = der * rp - nu * g * inv;
           }
           rp *= inv;
         }
@@ -233,7 +236,7 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
     }
     if (powers) {   // rows of one axis: [q] = u^q
       const double u0 = h == 0 ? w.nbx[n] : w.nbz[n];
-      double *pc = col + (size_t) (kp->pow_row + (h == 0 ? 0 : 2 * P)) * PITCH;
+      double *pc = col + mul24(kp->pow_row + (h == 0 ? 0 : 2 * P), PITCH);
       double cur = 1.0;
       pc[0] = 1.0;
       for (int q = 1; q < P; q++) {
@@ -242,7 +245,7 @@ __device__ __forceinline__ void build_tile(KP kp, const BlockTables &bt, const W
       }
       if (h == 0) {
         const double u1 = w.nby[n];
-        pc += (size_t) P * PITCH;
+        pc += mul24(P, PITCH);
         cur = 1.0;
         pc[0] = 1.0;
         for (int q = 1; q < P; q++) {
@@ -266,7 +269,7 @@ __device__ __forceinline__ void fp_from_parked(KP kp, const WaveLds<PITCH> &w, i
 #pragma unroll
     for (int mi = 0; mi < MTP_PARK; mi++) {
       const int mu = 2 * mi + h;
-      if (mu < Mu) col[mu * PITCH] = park[mi];
+      if (mu < Mu) col[mul24(mu, PITCH)] = park[mi];
     }
   }
   wave_fence();
@@ -590,7 +593,7 @@ __device__ __forceinline__ void force_degree(KP kp, unsigned pcol, unsigned pcoe
           // the slot, hence mu, is wave-uniform in this pass
           const int mu = (NODG || GRADE) ? __builtin_amdgcn_readfirstlane(smu[s0 + it]) : 0;
           const double g = lds_ld(cg, 0);
-          const double dg = NODG ? lds_ld(pfp + 8u * (unsigned) (mu * PITCH), 0) : lds_ld(cg + dgo, 0);   // NODG: f'_mu
+          const double dg = NODG ? lds_ld(pfp + 8u * (unsigned) (mu * PITCH), 0) : lds_ld(cg + dgo, 0);   // NODG: f'_mu (mu: SGPR)
           const double G = poly_eval<C>(ca, m);
           UA = fma(g, G, UA);
           VA = fma(dg * (NODG ? rwn : inv_nu), G, VA);
@@ -609,12 +612,13 @@ __device__ __forceinline__ void force_degree(KP kp, unsigned pcol, unsigned pcoe
         const int si = 2 * it + part;
         const bool ok = si < cnt;
         const int sc = ok ? si : 0;
-        const unsigned cb = pcoef + 8u * (unsigned) (kp->deg_coef[NU] + sc * 3 * C + C);
-        const unsigned cg = pcol + 8u * (unsigned) ((s0 + sc) * PITCH);
+        // (per-lane sc: 24-bit multiplies are full rate, 32-bit ones a quarter of it)
+        const unsigned cb = pcoef + 8u * (unsigned) (kp->deg_coef[NU] + C) + (unsigned) mul24(sc, 8 * 3 * C);
+        const unsigned cg = pcol + (unsigned) mul24(s0 + sc, 8 * PITCH);
         // (the halves hold different slots, hence different mu: a per-lane value here)
         const int mu_raw = (NODG || GRADE) ? smu[s0 + sc] : 0;
         const double g_raw = lds_ld(cg, 0);
-        const double dg_raw = NODG ? lds_ld(pfp + 8u * (unsigned) (mu_raw * PITCH), 0) : lds_ld(cg + dgo, 0);
+        const double dg_raw = NODG ? lds_ld(pfp + (unsigned) mul24(mu_raw, 8 * PITCH), 0) : lds_ld(cg + dgo, 0);
         const double G = poly_eval<C>(cb, m);
         const double g = ok ? g_raw : 0.0, dg = ok ? dg_raw : 0.0;
         UB = fma(g, G, UB);
@@ -711,10 +715,11 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       const unsigned w0 = (unsigned) bd[0], w1 = (unsigned) bd[1], w2 = (unsigned) bd[2];
 #pragma unroll
       for (int h = 0; h < 3; h++) {
-        hg[t][h] = w.addr(w.tab + (size_t) ((w0 >> (8 * h)) & 255u) * PITCH + q);
-        hx[t][h] = w.addr(w.tab + (size_t) (kp->pow_row + ((w1 >> (4 * h)) & 15u)) * PITCH + q);
-        ty[t][h] = w.addr(w.tab + (size_t) (kp->pow_row + P + ((w1 >> (12 + 4 * h)) & 15u)) * PITCH + q);
-        tz[t][h] = w.addr(w.tab + (size_t) (kp->pow_row + 2 * P + ((w2 >> (4 * h)) & 15u)) * PITCH + q);
+        const unsigned tq = w.addr(w.tab + q);
+        hg[t][h] = tq + (unsigned) mul24((int) ((w0 >> (8 * h)) & 255u), 8 * PITCH);
+        hx[t][h] = tq + (unsigned) mul24(kp->pow_row + (int) ((w1 >> (4 * h)) & 15u), 8 * PITCH);
+        ty[t][h] = tq + (unsigned) mul24(kp->pow_row + P + (int) ((w1 >> (12 + 4 * h)) & 15u), 8 * PITCH);
+        tz[t][h] = tq + (unsigned) mul24(kp->pow_row + 2 * P + (int) ((w2 >> (4 * h)) & 15u), 8 * PITCH);
         // one finished address per register: stops the optimiser from re-splitting them into
         // base + row offset (which costs a v_add per LDS read in the inner loops)
         asm volatile("" : "+v"(hg[t][h]), "+v"(hx[t][h]), "+v"(ty[t][h]), "+v"(tz[t][h]));
@@ -773,7 +778,8 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
       for (int u = 0; u < 2; u++) jpre[u] = kp->neigh[jbeg + min(64 * u + lane, jnum - 1)];
     }
     const int itype_raw = kp->type[i];
-    const double x0_raw = kp->x[3 * (size_t) i], x1_raw = kp->x[3 * (size_t) i + 1], x2_raw = kp->x[3 * (size_t) i + 2];
+    const double *xi_p = kp->x + 3 * (size_t) i;   // (i in SGPRs: scalar arithmetic)
+    const double x0_raw = xi_p[0], x1_raw = xi_p[1], x2_raw = xi_p[2];
     asm volatile("" : "+v"(jpre[0]), "+v"(jpre[1]));   // (pins the first use of the ids behind the requests above)
     const int itype = __builtin_amdgcn_readfirstlane(itype_raw) - 1;
     const double xi0 = uniform_f64(x0_raw), xi1 = uniform_f64(x1_raw), xi2 = uniform_f64(x2_raw);
@@ -800,9 +806,10 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         jt2[u] = kp->type[j2[u]] - 1;
-        d2[u][0] = kp->x[3 * (size_t) j2[u]];
-        d2[u][1] = kp->x[3 * (size_t) j2[u] + 1];
-        d2[u][2] = kp->x[3 * (size_t) j2[u] + 2];
+        const double *xj = row3(kp->x, j2[u]);
+        d2[u][0] = xj[0];
+        d2[u][1] = xj[1];
+        d2[u][2] = xj[2];
       }
       // (no branch on the loaded values ahead of the arithmetic: the compiler otherwise sinks the position loads of the
       // first entry behind its type check -- one more dependent memory round trip per atom)
@@ -1091,8 +1098,11 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
         const double Fx = part ? 0.0 : Fa, Fz = part ? Fa : 0.0;
         if (valid) {
           const size_t j = (size_t) w.nbj[n];
-          force_add(kp, 3 * j + (part ? 2 : 0), -Fa);   // pair_mtp.cpp:252-254
-          if (part == 0) force_add(kp, 3 * j + 1, -Fy);
+          unsigned j2 = (unsigned) j << 1;
+          asm volatile("" : "+v"(j2));
+          const size_t j3 = (size_t) (j2 + (unsigned) j);   // 3 j without a quarter-rate multiply
+          force_add(kp, j3 + (part ? 2 : 0), -Fa);   // pair_mtp.cpp:252-254
+          if (part == 0) force_add(kp, j3 + 1, -Fy);
         }
         // ---- totals of this tile over the 64 lanes: force on i (3), virial (6); lane v < 9 ends up with value v.
         // Per tile, not per atom: nine running sums carried across the tile loop would be live through the whole
