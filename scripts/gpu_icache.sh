@@ -5,13 +5,13 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1
 rocprofv3 -L 2>/dev/null | grep -i -E "ICACHE|IFETCH|INST_LEVEL|SQC_" | head -40 > $OUT/avail.txt
-for wl in small2k w16; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT/$wl -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-whole-step --workload $wl > $OUT/$wl.json 2> $OUT/$wl.err
+for wl in ${WLS:-small2k w16}; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVES SQ_WAVE_CYCLES SQC_TC_INST_REQ --output-format csv -d $OUT/$wl -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-whole-step --workload $wl > $OUT/$wl.json 2> $OUT/$wl.err
   echo "$wl rc=$?"
 done
 python - <<PY
 import csv, glob, collections
-for wl in ("small2k", "w16"):
+for wl in "${WLS:-small2k w16}".split():
     acc = collections.defaultdict(list)
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % wl, recursive=True):
         for row in csv.DictReader(open(f)):

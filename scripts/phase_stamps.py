@@ -27,10 +27,13 @@ f = torch.zeros((s.nall, 3), dtype=torch.float64, device=dev)
 ev = torch.zeros(8, dtype=torch.float64, device=dev)
 L = capi.lib()
 buf = (C.c_ulonglong * 16)()
-for it in range(3):
+import time
+ctx.set_timing(True)
+for it in range(12):
     ctx.compute_device(x, ty, f, eflag=1, vflag=1, ev_t=ev)
     ctx.synchronize()
     L.mtp_debug_read_stamps(ctx.h, buf)
+print("kernel ms (HIP events, stamped build): %.4f" % ctx.last_kernel_ms())
 names = ["loop head", "compaction", "tile tables", "basic moments", "products fwd", "energy+seeds", "products bwd",
          "forces", "totals", "coef blocks"]
 v = np.array(list(buf)[:10], dtype=float)
