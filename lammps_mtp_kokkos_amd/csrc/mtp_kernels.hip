@@ -480,7 +480,6 @@ __device__ __forceinline__ void gather_groups(const MtpRow8 *rp, int ngroups, co
   constexpr int G = CS >= 4 ? 1 : 4 / CS;    // chunks in flight
   constexpr int PARTS = CS / U;              // trips per chunk (CS = 8: two)
   const int ntrip = ((ngroups + G - 1) / G) * PARTS;
-  MtpRow8 nxt[G][U];
   auto fetch = [&](int trip, MtpRow8 (&dst)[G][U]) {
     const int g0 = (trip / PARTS) * G, part = trip % PARTS;
 #pragma unroll
@@ -488,10 +487,11 @@ __device__ __forceinline__ void gather_groups(const MtpRow8 *rp, int ngroups, co
 #pragma unroll
       for (int u = 0; u < U; u++) dst[j][u] = rp[64 * (min(g0 + j, ngroups - 1) * CS + part * U + u)];
   };
-  fetch(0, nxt);
   double acc[G];
 #pragma unroll
   for (int j = 0; j < G; j++) acc[j] = 0.0;
+  MtpRow8 nxt[G][U];
+  fetch(0, nxt);
   for (int trip = 0; trip < ntrip; trip++) {
     MtpRow8 cur[G][U];
 #pragma unroll
@@ -1707,6 +1707,7 @@ const char *mtp_kernel_build_flags()
 #if MTP_POLY_ACC != 1
       "MTP_POLY_ACC=" MTP_STR(MTP_POLY_ACC) " "
 #endif
+
 #if MTP_GRADE_TPB != 512 || MTP_GRADE_WPE != 2
       "MTP_GRADE_TPB=" MTP_STR(MTP_GRADE_TPB) " "
 #endif
