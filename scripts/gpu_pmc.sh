@@ -19,6 +19,7 @@ run sq3 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALI
 run tcc1 FETCH_SIZE
 run tcc2 WRITE_SIZE
 run tcc3 TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum
+run mfma SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline $ARGS > $OUT/stats.json 2> $OUT/stats.err; echo "stats rc=$?"
 find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} $OUT/kernel_stats.csv
 head -8 $OUT/kernel_stats.csv
@@ -29,7 +30,7 @@ from lammps_mtp_kokkos_amd import capi
 args = "$ARGS".split()
 workload = args[args.index("--workload") + 1] if "--workload" in args else "w16"
 tot, others = {}, collections.defaultdict(dict)
-for name in ["sq1","sq2","sq3","tcc1","tcc2","tcc3"]:
+for name in ["sq1","sq2","sq3","tcc1","tcc2","tcc3","mfma"]:
     files = glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True)
     acc = collections.defaultdict(list)
     for f in files:
