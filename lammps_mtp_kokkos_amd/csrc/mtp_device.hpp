@@ -78,7 +78,7 @@ struct MtpDevParams {
   long long *fq;           // deterministic mode: [nall][3] fixed-point force accumulators (else null)
   double *eatom;           // [nall] or null
   double *vatom;           // [nall][6] or null
-  double *ev_slots;        // [MTP_EV_SLOTS][8]
+  double *ev_slots;        // [8][MTP_EV_SLOTS], quantity-major
   double *cvec;            // [inum][cpad] candidate vectors dE_i/dtheta (grade calls only)
   int cpad;                // row stride of cvec and of the padded inverse active set (multiple of 16)
   double *dbasic;          // [inum][dpad] adjoints of the basics, zero padded (grade calls only)

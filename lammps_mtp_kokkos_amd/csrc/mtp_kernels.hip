@@ -1186,8 +1186,9 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     if (lane == 9) tally += et;
   }
   if (lane >= 3 && lane <= 9 && tally != 0.0) {
-    double *slot = kp->ev_slots + 8 * (size_t) ((blockIdx.x * wpb + wave) % MTP_EV_SLOTS);
-    unsafeAtomicAdd(&slot[lane == 9 ? 0 : lane - 2], tally);
+    // quantity-major slots [8][MTP_EV_SLOTS]: the fold reads each quantity's slots as one contiguous run
+    double *slot = kp->ev_slots + (size_t) ((blockIdx.x * wpb + wave) % MTP_EV_SLOTS);
+    unsafeAtomicAdd(&slot[(size_t) (lane == 9 ? 0 : lane - 2) * MTP_EV_SLOTS], tally);
   }
 }
 
@@ -1211,8 +1212,8 @@ __global__ void __launch_bounds__(512) mtp_ev_finish(double *ev_slots, double *e
   const int q = blockIdx.x;   // 0..6
   double s = 0.0;
   for (int k = threadIdx.x; k < MTP_EV_SLOTS; k += 512) {
-    s += ev_slots[8 * (size_t) k + q];
-    ev_slots[8 * (size_t) k + q] = 0.0;
+    s += ev_slots[(size_t) q * MTP_EV_SLOTS + k];
+    ev_slots[(size_t) q * MTP_EV_SLOTS + k] = 0.0;
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
@@ -1245,8 +1246,8 @@ __global__ void __launch_bounds__(512) mtp_ev_finish_unpack(double *ev_slots, do
   const int q = blockIdx.x;   // 0..6
   double s = 0.0;
   for (int k = threadIdx.x; k < MTP_EV_SLOTS; k += 512) {
-    s += ev_slots[8 * (size_t) k + q];
-    ev_slots[8 * (size_t) k + q] = 0.0;
+    s += ev_slots[(size_t) q * MTP_EV_SLOTS + k];
+    ev_slots[(size_t) q * MTP_EV_SLOTS + k] = 0.0;
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
