@@ -9,10 +9,12 @@
 // into the mirror's views and its results back, and turns mtp_mi355x::Error into error->all / error->one.
 //
 // COMPILE-GATED: needs a LAMMPS source tree (not present in this repository's build image):
-//   hipcc/g++ -std=c++17 -fPIC -shared -DLAMMPS_SOURCE_DIR_AVAILABLE [-DLMP_KOKKOS] -I$LAMMPS_SOURCE_DIR/src \
-//       [-I$LAMMPS_SOURCE_DIR/src/KOKKOS -I<kokkos include dirs>] -I$REPO/include pair_mtp_mi355x_plugin.cpp \
+//   hipcc/g++ -std=c++17 -fPIC -shared -DLAMMPS_SOURCE_DIR_AVAILABLE [-DLMP_KOKKOS] -I$LAMMPS_SOURCE_DIR/src
+//       [-I$LAMMPS_SOURCE_DIR/src/KOKKOS -I<kokkos include dirs>] -I$REPO/include pair_mtp_mi355x_plugin.cpp
 //       -L$REPO/lammps_mtp_kokkos_amd -lpair_mtp_mi355x -lmtp_mi355x -o libmtp_mi355x_lammps.so
-// It has not been compiled against LAMMPS here; INTEGRATION.md lists what to check first.
+// It has not been compiled against LAMMPS here; INTEGRATION.md lists what to check first.  What IS done here: the
+// non-KOKKOS branch is compiled against a mock of the API surface it touches (tests/cpp/lammps_mock/, test scaffolding
+// written for this purpose) and driven through LAMMPS' call sequence on the GPU (tests/cpp/test_plugin_mock.cpp).
 #ifdef LAMMPS_SOURCE_DIR_AVAILABLE
 
 #include "atom.h"

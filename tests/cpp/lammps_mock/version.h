@@ -1,0 +1,3 @@
+// MOCK (see lammps_mock.h)
+#pragma once
+#include "lammps_mock.h"

@@ -198,3 +198,71 @@ def test_extrapolation_kk_style_keeps_grades_on_the_device_until_asked(tmp_path)
     assert abs(float(lines[0].split()[2]) - mg) < 1e-9 * max(1, mg)
     g = np.array(lines[1:1 + s.nlocal], float)
     assert np.abs(g - want["grades"][: s.nlocal]).max() < 1e-9 * max(1, mg)
+
+
+# ---- the LAMMPS plugin adapter, compiled against the mock of the LAMMPS API (tests/cpp/lammps_mock) ------------------
+
+PLUGIN_EXE = os.path.join(ROOT, "tests", "cpp", "test_plugin_mock")
+
+
+def test_plugin_adapter_compiles_and_registers_the_six_reference_styles():
+    """lammpsplugin_init -> six `pair` registrations with the reference's style names (pair_mtp.h:18-21,
+    pair_mtp_extrapolation.h:18-21, KOKKOS/pair_mtp*_kokkos.h:18-23).  The mock is test scaffolding: this pins that the
+    adapter compiles and registers, not compatibility with a LAMMPS binary."""
+    _build()
+    r = subprocess.run([PLUGIN_EXE, "list"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    names = r.stdout.split("\n")[:6]
+    assert sorted(names) == sorted(["mtp", "mtp/kk", "mtp/small/kk", "mtp/extrapolation", "mtp/extrapolation/kk",
+                                    "mtp/extrapolation/small/kk"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("style,extra", [("mtp", []), ("mtp/kk", ["chunksize", "32768"])])
+def test_plugin_adapter_walks_the_lammps_call_sequence(tmp_path, style, extra):
+    """creator -> settings -> coeff -> init_style (REQ_FULL request) -> init_one -> compute(ENERGY_GLOBAL | ENERGY_ATOM,
+    VIRIAL_FDOTR | VIRIAL_ATOM) through the adapter: forces, eng_vdwl, eatom, virial (tallied although LAMMPS asked for
+    FDOTR: no_virial_fdotr_compute is set, pair_mtp.cpp:257) and vatom against the oracle."""
+    from oracle.pyoracle import Oracle
+    _build()
+    pos, box = mtpgen.bcc_lattice(4, 4, 4)
+    s = periodic_system(pos, box, None, 7.0)
+    sysf, outf = str(tmp_path / "sys.txt"), str(tmp_path / "out.txt")
+    _write_system(sysf, s)
+    potf = os.path.join(POT, "W_L16.mtp")
+    r = subprocess.run([PLUGIN_EXE, "run", style, sysf, outf, potf] + extra, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "The scaling is : 1.00e+00." in r.stdout and "There are 1 species." in r.stdout      # utils::logmesg lines
+    lines = open(outf).read().split("\n")
+    e, cut, flags = lines[0].split()
+    assert float(cut) == 5.0 and flags == "11100"     # no_virial_fdotr_compute, manybody, one_coeff set; single, restart off
+    vir = np.array(lines[1].split(), float)
+    arr = np.array([l.split() for l in lines[2:2 + s.nall]], float)
+    want = Oracle(potf).compute(s.x, s.types, s.ilist, s.first, s.neigh, eflag=3, vflag=4)
+    assert abs(float(e) - want["energy"]) < 1e-9
+    assert np.abs(arr[:, :3] - want["f"]).max() < 1e-9
+    assert np.abs(arr[:, 3] - want["eatom"]).max() < 1e-10
+    assert np.abs(arr[:, 4] - want["vatom"][:, 0]).max() < 1e-9
+    assert np.abs(vir - want["virial"]).max() < 1e-8 and np.abs(vir).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_plugin_adapter_extrapolation_style_fix_pair_protocol(tmp_path):
+    from oracle.pyoracle import Oracle
+    _build()
+    pos, box = mtpgen.bcc_lattice(3, 3, 3)
+    s = periodic_system(pos, box, None, 7.0)
+    sysf, outf = str(tmp_path / "sys.txt"), str(tmp_path / "out.txt")
+    _write_system(sysf, s)
+    potf = os.path.join(POT, "W_L16_nbh.almtp")
+    want = Oracle(potf, selection=True).compute(s.x, s.types, s.ilist, s.first, s.neigh, extrapolation=True)
+    r = subprocess.run([PLUGIN_EXE, "run", "mtp/extrapolation", sysf, outf, potf], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Extrapolation Mode: Neighborhood mode." in r.stdout
+    lines = open(outf).read().split("\n")
+    e, e_first, pv, nextra = lines[0].split()
+    mg = want["max_grade"]
+    assert abs(float(e) - want["energy"]) < 1e-9 and abs(float(e_first) - want["energy"]) < 1e-9 and nextra == "1"
+    assert abs(float(pv) - mg) < 1e-9 * max(1, mg)
+    g = np.array(lines[1:1 + s.nlocal], float)
+    assert np.abs(g - want["grades"][: s.nlocal]).max() < 1e-9 * max(1, mg)
