@@ -280,8 +280,8 @@ void mtp_context::plan()
         // the table blob, fewer workgroups to dispatch: 2,048 atoms in 256 workgroups of 8 wavefronts run 3 % faster than
         // in 1,024 of 2); narrower only when the atoms would not cover the CUs
         int pick_w = 0;
-        for (int w = 1; w <= best_w; w++)
-          if ((long long) num_cus * waves2(w, wb) >= inum && (inum + w - 1) / w >= num_cus) pick_w = w;
+        for (int w = 1; w <= 8; w++)
+          if (waves2(w, wb) > 0 && (long long) num_cus * waves2(w, wb) >= inum && (inum + w - 1) / w >= num_cus) pick_w = w;
         if (pick_w == 0)
           for (int w = 1; w < best_w && pick_w == 0; w++)
             if ((long long) num_cus * waves2(w, wb) >= inum) pick_w = w;
