@@ -669,8 +669,45 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
 
   (void) p_arg;   // the only kernel argument: it starts the kernarg segment
   KP kp = (KP) __builtin_amdgcn_kernarg_segment_ptr();
+  kernarg_touch<(int) sizeof(MtpDevParams)>(kp);
   extern __shared__ double lds[];
   unsigned char *sh = reinterpret_cast<unsigned char *>(lds);
+  const int lane = threadIdx.x & 63;
+  // wave-uniform by construction: tell the compiler, so per-atom state lives in SGPRs
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wpb = blockDim.x >> 6;
+
+  // XCD-aware atom map: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b works
+  // for XCD b % 8; giving every XCD one contiguous eighth of ilist (callers keep atoms roughly in spatial order:
+  // LAMMPS sorts them, the bench lattice is cell-major) keeps the position gathers and the force atomics of a slab in
+  // ONE L2 instead of spreading every slab over all eight.
+  int ii_beg, ii_end, ii_step;
+  if (kp->xcd_map && (gridDim.x & 7) == 0) {
+    const int chunk = (kp->inum + 7) >> 3, xcd = blockIdx.x & 7;
+    // Rounds of (workgroups x wpb) atoms: when the last round is only partly filled, the wavefronts are numbered
+    // wave-major, so that its atoms land on a few wavefronts of EVERY workgroup instead of on all wavefronts of a few
+    // (65 536 atoms over 3 072 wavefronts = 21.33 rounds: -2.4 %); with whole rounds the block-major numbering keeps
+    // neighbouring atoms on one CU (level 20, 32 rounds exactly: 0.3 % better).
+    const int nb8 = gridDim.x >> 3;
+    if (chunk % (nb8 * wpb) != 0) ii_beg = kp->row0 + xcd * chunk + wave * nb8 + (blockIdx.x >> 3);
+    else ii_beg = kp->row0 + xcd * chunk + (blockIdx.x >> 3) * wpb + wave;
+    ii_end = kp->row0 + min(kp->inum, (xcd + 1) * chunk);
+    ii_step = (gridDim.x >> 3) * wpb;
+  } else {
+    ii_step = gridDim.x * wpb;
+    if (kp->inum % ii_step != 0) ii_beg = kp->row0 + wave * gridDim.x + blockIdx.x;
+    else ii_beg = kp->row0 + blockIdx.x * wpb + wave;
+    ii_end = kp->row0 + kp->inum;
+  }
+  // The head of an atom's list row {ilist, first} is requested one atom ahead and carried in SGPRs: two dependent memory
+  // round trips per atom instead of three, and the first atom's ride on the table copy below (what a 2,048-atom call
+  // is made of: one atom per wavefront, every load a miss).
+  int hd_i = 0, hd_b = 0, hd_e = 0;
+  if (ii_beg < ii_end) {   // (uniform)
+    hd_i = kp->ilist[ii_beg];
+    hd_b = kp->first[ii_beg];
+    hd_e = kp->first[ii_beg + 1];
+  }
   // ---- 0. workgroup-shared tables ---------------------------------------------------------
   for (int o = threadIdx.x * 16; o < kp->blob_bytes; o += blockDim.x * 16)
     *reinterpret_cast<uint4 *>(sh + o) = *reinterpret_cast<const uint4 *>(kp->blob + o);
@@ -694,10 +731,6 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
   bt.leaf_cb = reinterpret_cast<const double *>(sh + kp->off_leaf_cb);
   const bool rows_lds = kp->rows_in_lds != 0;
 
-  const int lane = threadIdx.x & 63;
-  // wave-uniform by construction: tell the compiler, so per-atom state lives in SGPRs
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wpb = blockDim.x >> 6;
   const int kl = lane & (KL - 1), q = lane / KL;
   const unsigned wave_off = (kp->blob_bytes >> 3) + wave * kp->wave_doubles;   // doubles
   const unsigned lds0 = (unsigned) (size_t) (lds_cdouble *) lds;            // static cast of the array itself
@@ -748,36 +781,19 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
   unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #endif
 
-  // XCD-aware atom map: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b works
-  // for XCD b % 8; giving every XCD one contiguous eighth of ilist (callers keep atoms roughly in spatial order:
-  // LAMMPS sorts them, the bench lattice is cell-major) keeps the position gathers and the force atomics of a slab in
-  // ONE L2 instead of spreading every slab over all eight.
-  int ii_beg, ii_end, ii_step;
-  if (kp->xcd_map && (gridDim.x & 7) == 0) {
-    const int chunk = (kp->inum + 7) >> 3, xcd = blockIdx.x & 7;
-    // Rounds of (workgroups x wpb) atoms: when the last round is only partly filled, the wavefronts are numbered
-    // wave-major, so that its atoms land on a few wavefronts of EVERY workgroup instead of on all wavefronts of a few
-    // (65 536 atoms over 3 072 wavefronts = 21.33 rounds: -2.4 %); with whole rounds the block-major numbering keeps
-    // neighbouring atoms on one CU (level 20, 32 rounds exactly: 0.3 % better).
-    const int nb8 = gridDim.x >> 3;
-    if (chunk % (nb8 * wpb) != 0) ii_beg = kp->row0 + xcd * chunk + wave * nb8 + (blockIdx.x >> 3);
-    else ii_beg = kp->row0 + xcd * chunk + (blockIdx.x >> 3) * wpb + wave;
-    ii_end = kp->row0 + min(kp->inum, (xcd + 1) * chunk);
-    ii_step = (gridDim.x >> 3) * wpb;
-  } else {
-    ii_step = gridDim.x * wpb;
-    if (kp->inum % ii_step != 0) ii_beg = kp->row0 + wave * gridDim.x + blockIdx.x;
-    else ii_beg = kp->row0 + blockIdx.x * wpb + wave;
-    ii_end = kp->row0 + kp->inum;
-  }
+  int nx_i = __builtin_amdgcn_readfirstlane(hd_i), nx_b = __builtin_amdgcn_readfirstlane(hd_b);
+  int nx_n = __builtin_amdgcn_readfirstlane(hd_e) - nx_b;
   for (int ii = ii_beg; ii < ii_end; ii += ii_step) {
-    // ii is wave-uniform, so is everything loaded through it: keep it in SGPRs.  Three dependent memory round trips
-    // per atom: {ilist, first} -> {type_i, x_i, the row's first 128 neighbour ids} -> {x_j, type_j}: every load of a
-    // stage is requested before the first wait, and before the type check branches.
-    const int i_raw = kp->ilist[ii], jbeg_raw = kp->first[ii], jend_raw = kp->first[ii + 1];
-    const int i = __builtin_amdgcn_readfirstlane(i_raw);
-    const int jbeg = __builtin_amdgcn_readfirstlane(jbeg_raw);
-    const int jnum = __builtin_amdgcn_readfirstlane(jend_raw) - jbeg;
+    // ii is wave-uniform, so is everything loaded through it: keep it in SGPRs.  Two dependent memory round trips per
+    // atom: {type_i, x_i, the row's first 128 neighbour ids; the NEXT atom's ilist, first} -> {x_j, type_j}: every load
+    // of a stage is requested before the first wait, and before the type check branches.
+    const int i = nx_i, jbeg = nx_b, jnum = nx_n;
+    {
+      const int iin = min(ii + ii_step, ii_end - 1);   // (the last atom asks for its own row again: no branch)
+      hd_i = kp->ilist[iin];
+      hd_b = kp->first[iin];
+      hd_e = kp->first[iin + 1];
+    }
     int jpre[2] = {0, 0};   // neighbour ids of the first chunk
     if (jnum > 0) {         // (uniform)
 #pragma unroll
@@ -789,6 +805,9 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
     asm volatile("" : "+v"(jpre[0]), "+v"(jpre[1]));   // (pins the first use of the ids behind the requests above)
     const int itype = __builtin_amdgcn_readfirstlane(itype_raw) - 1;
     const double xi0 = uniform_f64(x0_raw), xi1 = uniform_f64(x1_raw), xi2 = uniform_f64(x2_raw);
+    nx_i = __builtin_amdgcn_readfirstlane(hd_i);   // (requested ahead of the loads above: here by now)
+    nx_b = __builtin_amdgcn_readfirstlane(hd_b);
+    nx_n = __builtin_amdgcn_readfirstlane(hd_e) - nx_b;
     if (itype < 0 || itype >= kp->Sp) {   // pair_mtp.cpp:91-93
       if (lane == 0) atomicExch(kp->err_flag, 1);
       continue;
