@@ -140,6 +140,31 @@ def test_ragged_lists_empty_rows_and_subset_ilist():
     _compare(os.path.join(POT, "W_L16.mtp"), s)
 
 
+@pytest.mark.parametrize("name", ["W_L16.mtp", "WRe_L20.mtp"])
+def test_every_row_empty_isolated_atoms(name):
+    """No atom has a neighbour and the id array has NO entries at all (pair_mtp.cpp:107-109 with jnum = 0 everywhere):
+    site energies are the species coefficients plus the scalars of all-zero moments, forces and virial are zero.  The
+    atom loop requests the next atom's ids one atom ahead: an empty row must not make it read them."""
+    s = _system((3, 3, 3), species=2 if name.startswith("WRe") else 1)
+    s.ilist = np.arange(s.nlocal, dtype=np.int32)
+    s.first = np.zeros(s.nlocal + 1, np.int32)
+    s.neigh = np.zeros(0, np.int32)
+    got, want, _ = _compare(os.path.join(POT, name), s)
+    assert not got["f"].any() and not got["virial"].any()
+
+
+def test_rows_with_neighbours_only_at_the_end_of_the_list():
+    """every row empty except the LAST one (the row whose ids sit at the very end of the id array)"""
+    s = _system((3, 3, 3))
+    last = s.nlocal - 1
+    row = s.neigh[s.first[last]:s.first[last + 1]].copy()
+    s.ilist = np.arange(s.nlocal, dtype=np.int32)
+    first = np.zeros(s.nlocal + 1, np.int32)
+    first[-1] = len(row)
+    s.first, s.neigh = first, row
+    _compare(os.path.join(POT, "W_L16.mtp"), s)
+
+
 def test_empty_ilist():
     s = _system((2, 2, 2))
     pot = capi.Potential(os.path.join(POT, "W_L8.mtp"))
