@@ -272,6 +272,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_step()
+    t_issue = time.perf_counter() - t0      # the host's share: when this approaches dt the GPU waits for launches
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -452,7 +453,10 @@ def main():
                        if decomposed else ("single GPU, step replayed from a HIP graph" if run_step is not step else "single GPU"),
                        "atoms_rank0": plan.nlocal, "ghosts_rank0": plan.nghost, "list_entries_rank0": int(plan.first[-1]),
                        "in_cutoff_pairs_rank0": jc_total, "launch": info, "halo_schedule_probe": schedule_probe,
-                       "device_list_build_ms": list_build_ms},
+                       "device_list_build_ms": list_build_ms,
+                       # host time to ENQUEUE a step (python -> ctypes -> HIP launches), rank 0: the GPU waits for the
+                       # host when this approaches ms_per_step
+                       "host_issue_ms_per_step": t_issue / args.steps * 1e3},
             # The governing bound of the fused kernel is fp64 vector issue, so that is what `achieved` /
             # `peak` / `frac` price: the REFERENCE algorithm's flop count F_alg per launch over the kernel time measured
             # here with HIP events.  The HBM side (the contract's default bound) is the `hbm` sub-block: algorithmic bytes

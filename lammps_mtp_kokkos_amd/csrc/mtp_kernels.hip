@@ -669,6 +669,9 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
 
   (void) p_arg;   // the only kernel argument: it starts the kernarg segment
   KP kp = (KP) __builtin_amdgcn_kernarg_segment_ptr();
+#ifdef MTP_STAMPS
+  const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
+#endif
   kernarg_touch<(int) sizeof(MtpDevParams)>(kp);
   extern __shared__ double lds[];
   unsigned char *sh = reinterpret_cast<unsigned char *>(lds);
@@ -779,6 +782,7 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
 #ifdef MTP_STAMPS
   unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_prologue = st_prev - st_entry;   // argument block, table copy, barrier, first list head
 #endif
 
   int nx_i = __builtin_amdgcn_readfirstlane(hd_i), nx_b = __builtin_amdgcn_readfirstlane(hd_b);
@@ -1193,6 +1197,11 @@ __global__ void __launch_bounds__(WPS == 3 ? 768 : 512, WPS) mtp_wave_kernel(con
 #ifdef MTP_STAMPS
   if (lane == 0 && kp->stamps)
     for (int k = 0; k < 10; k++) atomicAdd(kp->stamps + k, st_acc[k]);
+  if (lane == 0 && kp->stamps) {
+    atomicAdd(kp->stamps + 10, st_prologue);
+    atomicAdd(kp->stamps + 11, __builtin_amdgcn_s_memtime() - st_entry);   // the wavefront's life up to here
+    atomicAdd(kp->stamps + 12, 1ull);                                        // wavefronts
+  }
 #endif
   if (kp->vflag && !v_per_atom) {   // the deferred virial: one transpose-reduce for all atoms of the wavefront
     double part16[16] = {0.0, 0.0, 0.0, vacc[0], vacc[1], vacc[2], vacc[3], vacc[4], vacc[5], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};

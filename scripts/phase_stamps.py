@@ -12,12 +12,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lammps_mtp_kokkos_amd import capi, mtpgen  # noqa: E402
 from lammps_mtp_kokkos_amd.driver import periodic_system  # noqa: E402
 
-cells = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+cells = [int(c) for c in sys.argv[1].split("x")] if len(sys.argv) > 1 else [32]   # "32" or "8x8x16"
+cells = cells * 3 if len(cells) == 1 else cells
 potf = sys.argv[2] if len(sys.argv) > 2 else "potentials/W_L16.mtp"
-pos, box = mtpgen.bcc_lattice(cells, cells, cells)
+variant = sys.argv[3] if len(sys.argv) > 3 else None                               # "small" | "large"
+pos, box = mtpgen.bcc_lattice(*cells)
 s = periodic_system(pos, box, None, 7.0)
 pot = capi.Potential(potf)
 ctx = capi.Context(pot, 0)
+if variant:
+    ctx.set_variant(dict(auto=0, large=1, small=2)[variant])
 dev = torch.device("cuda:0")
 il, fi, ne = (torch.from_numpy(a).to(dev) for a in (s.ilist, s.first, s.neigh))
 ctx.set_neighbors_device(il, fi, ne, s.nall, int(np.diff(s.first).max()))
@@ -41,3 +45,6 @@ print("launch", ctx.launch_info())
 for n, c in zip(names, v):
     print("%-14s %6.2f %%   %8.0f cycles/atom" % (n, 100 * c / v.sum(), c / s.nlocal))
 print("sum %.0f cycles/atom/wave" % (v.sum() / s.nlocal))
+nw = max(1, int(buf[12]))
+print("per wavefront (%d wavefronts): prologue %.0f cycles, entry -> end of the atom loop %.0f cycles, atoms %.2f" % (
+    nw, buf[10] / nw, buf[11] / nw, s.nlocal / nw))
