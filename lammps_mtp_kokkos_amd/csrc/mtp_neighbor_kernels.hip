@@ -2,14 +2,19 @@
 // the pair style through list->ilist / numneigh / firstneigh (pair_mtp.cpp:81-85, REQ_FULL at :317-318), built on
 // the GPU for drivers that keep positions in HBM.  Cell list with cells of one list cutoff:
 //
-//   bin       cell id per atom (owned + ghosts), histogram with global atomics
-//   scan      exclusive prefix over the cells (hipcub)
-//   sort      stable radix sort of (cell id, atom id) pairs (hipcub): atoms in cell order, ids ascending inside a cell
-//             (deterministic lists)
+//   bin       cell id per atom (owned + ghosts), histogram with global atomics; ilist = 0 .. inum-1
+//   scan      exclusive prefix over the cells: ONE workgroup (grids up to 65 536 cells; hipcub above that)
+//   place     atoms into their cell's segment in the order the atomics land ...
+//   order     ... then one wavefront per cell ranks the ids of its segment (ids ascending inside a cell: the list
+//             never depends on the order in which atomics landed) and writes the positions in cell order
+//             (grids above 65 536 cells: a stable hipcub radix sort of (cell id, atom id) pairs + a gather instead)
 //   count     one WAVEFRONT per cell: 64 candidates of the 27 surrounding cells at a time against every owned atom
 //             of the cell (ballot + popcount): number of atoms with r^2 <= cut^2
-//   scan      row offsets first[inum + 1]
+//   scan      row offsets first[inum + 1] (hipcub)
 //   fill      the same walk writing neigh[] (prefix popcount = place in the row)
+//
+// Round 3: the round-2 build was 22 launches (rocprim radix sort = 7, three fills, iota, gather, two scans); this one
+// is 10, and the placement costs three small kernels instead of a sort of all atoms.
 //
 // Integer work only after the distance test: the rows hold exactly the atoms j != i with |x_j - x_i|^2 <= cut^2
 // (tests compare them as sets with a host KD-tree list).  HBM-bound and tiny next to a force call.
@@ -38,8 +43,8 @@ __device__ __forceinline__ void cell_of(const CellGrid &g, const double *x, int 
   }
 }
 
-__global__ void nb_bin(CellGrid g, const double *__restrict__ x, int nall, int *__restrict__ cell_id,
-                       int *__restrict__ cell_count, int *__restrict__ iota)
+__global__ void nb_bin(CellGrid g, const double *__restrict__ x, int nall, int inum, int *__restrict__ cell_id,
+                       int *__restrict__ cell_count, int *__restrict__ iota, int *__restrict__ ilist)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nall) return;
@@ -47,8 +52,69 @@ __global__ void nb_bin(CellGrid g, const double *__restrict__ x, int nall, int *
   cell_of(g, x, i, c);
   const int id = (c[0] * g.n[1] + c[1]) * g.n[2] + c[2];
   cell_id[i] = id;
-  iota[i] = i;
+  if (iota) iota[i] = i;
+  if (i < inum) ilist[i] = i;
   atomicAdd(&cell_count[id], 1);
+}
+
+// Exclusive prefix over n <= 65 536 + 1 cell counts by ONE workgroup of 1 024 threads (a run of consecutive entries per
+// thread, the run totals scanned through LDS); cursor[c] = start[c] is left for nb_place.
+__global__ void __launch_bounds__(1024) nb_scan_cells(const int *count, int n, int *__restrict__ start, int *cursor)   // (cursor may be count)
+{
+  __shared__ int part[1024];
+  const int t = threadIdx.x, per = (n + 1023) / 1024, b = min(t * per, n), e = min(b + per, n);
+  int sum = 0;
+  for (int k = b; k < e; k++) sum += count[k];
+  part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {   // Hillis-Steele over the 1 024 run totals
+    const int v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - sum;   // exclusive
+  for (int k = b; k < e; k++) {
+    const int c = count[k];
+    start[k] = run;
+    cursor[k] = run;
+    run += c;
+  }
+}
+
+__global__ void nb_place(const int *__restrict__ cell_id, int nall, int *__restrict__ cursor, int *__restrict__ unordered)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nall) unordered[atomicAdd(&cursor[cell_id[i]], 1)] = i;
+}
+
+// One wavefront per cell: the ids of the cell's segment are ranked (rank = number of smaller ids: they are distinct), so
+// the segment comes out ascending whatever order nb_place left it in; the positions follow in the same order.
+__global__ void __launch_bounds__(256) nb_order_cell(int ncell, const int *__restrict__ cell_start,
+                                                     const int *__restrict__ unordered, const double *__restrict__ x,
+                                                     int *__restrict__ cell_atoms, double *__restrict__ xs)
+{
+  const int lane = threadIdx.x & 63;
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (c >= ncell) return;
+  const int cs = __builtin_amdgcn_readfirstlane(cell_start[c]), ce = __builtin_amdgcn_readfirstlane(cell_start[c + 1]);
+  for (int b0 = cs; b0 < ce; b0 += 64) {
+    const bool have = b0 + lane < ce;
+    const int id = have ? unordered[b0 + lane] : 0x7fffffff;
+    int rank = 0;
+    for (int q0 = cs; q0 < ce; q0 += 64) {   // (uniform) every chunk of the segment against this one
+      const int other = q0 + lane < ce ? unordered[q0 + lane] : 0x7fffffff;
+      const int nq = min(64, ce - q0);
+      for (int e = 0; e < nq; e++) rank += __builtin_amdgcn_readlane(other, e) < id ? 1 : 0;
+    }
+    if (have) {
+      const size_t k = (size_t) cs + rank;
+      cell_atoms[k] = id;
+      xs[3 * k] = x[3 * (size_t) id];
+      xs[3 * k + 1] = x[3 * (size_t) id + 1];
+      xs[3 * k + 2] = x[3 * (size_t) id + 2];
+    }
+  }
 }
 
 // positions in cell order: the candidate chunks of nb_walk_cell then read contiguous memory
@@ -158,12 +224,6 @@ __global__ __launch_bounds__(256) void nb_walk_cell(CellGrid g, int inum, double
   }
 }
 
-__global__ void nb_iota(int *v, int n)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) v[i] = i;
-}
-
 // ---- LAMMPS-KOKKOS list view -> the internal CSR (mtp_set_neighbors_device_2d) -------------------------------------
 // counts[ii] = d_numneigh[d_ilist[ii]] (+ their maximum)
 __global__ void __launch_bounds__(256) nb2d_count(int inum, const int *__restrict__ ilist, const int *__restrict__ numneigh,
@@ -259,22 +319,33 @@ hipError_t mtp_launch_neighbor_build(const double *x, int inum, int nall, double
   if (const char *env = std::getenv("MTP_NB_SPLIT")) split4 = std::atoi(env) == 4;
   hipError_t e;
   if (!neigh) {
-    if ((e = hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t) (ncell + 1), st)) != hipSuccess) return e;
+    // cell_count[ncell + 1] and numneigh[inum + 1] are neighbours in the scratch: one fill for both
+    if ((e = hipMemsetAsync(cell_count, 0, sizeof(int) * ((size_t) ncell + 1 + (size_t) inum + 1), st)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(d_info, 0, 2 * sizeof(int), st)) != hipSuccess) return e;
-    if (nall > 0) hipLaunchKernelGGL(nb_bin, dim3((nall + T - 1) / T), dim3(T), 0, st, g, x, nall, cell_id, cell_count, iota);
-    if ((e = hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, cell_count, cell_start, ncell + 1, st)) != hipSuccess)
-      return e;
-    if (nall > 0) {
-      // atoms into cell order: a STABLE sort of (cell id, atom id) pairs keeps the ids ascending inside every cell, so
-      // the list order never depends on the order in which atomics land (deterministic lists)
-      int bits = 1;
-      while ((1ll << bits) < (long long) ncell) bits++;
-      if ((e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, cell_id, cell_id_sorted, iota, cell_atoms, nall, 0, bits,
-                                                  st)) != hipSuccess)
+    const bool one_block_scan = ncell <= 65536 && std::getenv("MTP_NB_SORT") == nullptr;   // (MTP_NB_SORT: tests run the sort path)
+    if (nall > 0)
+      hipLaunchKernelGGL(nb_bin, dim3((nall + T - 1) / T), dim3(T), 0, st, g, x, nall, inum, cell_id, cell_count,
+                         one_block_scan ? (int *) nullptr : iota, ilist);
+    if (one_block_scan) {
+      // cell_count doubles as the placement cursor once the prefix is taken
+      hipLaunchKernelGGL(nb_scan_cells, dim3(1), dim3(1024), 0, st, cell_count, ncell + 1, cell_start, cell_count);
+      if (nall > 0) {
+        hipLaunchKernelGGL(nb_place, dim3((nall + T - 1) / T), dim3(T), 0, st, cell_id, nall, cell_count, cell_id_sorted);
+        hipLaunchKernelGGL(nb_order_cell, dim3((ncell + 3) / 4), dim3(T), 0, st, ncell, cell_start, cell_id_sorted, x, cell_atoms, xs);
+      }
+    } else {
+      if ((e = hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, cell_count, cell_start, ncell + 1, st)) != hipSuccess)
         return e;
-      hipLaunchKernelGGL(nb_gather, dim3((nall + T - 1) / T), dim3(T), 0, st, x, cell_atoms, nall, xs);
+      if (nall > 0) {
+        // atoms into cell order: a STABLE sort of (cell id, atom id) pairs keeps the ids ascending inside every cell
+        int bits = 1;
+        while ((1ll << bits) < (long long) ncell) bits++;
+        if ((e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, cell_id, cell_id_sorted, iota, cell_atoms, nall, 0, bits,
+                                                    st)) != hipSuccess)
+          return e;
+        hipLaunchKernelGGL(nb_gather, dim3((nall + T - 1) / T), dim3(T), 0, st, x, cell_atoms, nall, xs);
+      }
     }
-    if ((e = hipMemsetAsync(numneigh, 0, sizeof(int) * (size_t) (inum + 1), st)) != hipSuccess) return e;
     if (inum > 0) {
       if (split4)
         hipLaunchKernelGGL((nb_walk_cell<false, 4>), dim3(ncell), dim3(T), 0, st, g, inum, cutoff * cutoff, ncell, cell_start,
@@ -282,7 +353,6 @@ hipError_t mtp_launch_neighbor_build(const double *x, int inum, int nall, double
       else
         hipLaunchKernelGGL((nb_walk_cell<false, 1>), dim3((ncell + 3) / 4), dim3(T), 0, st, g, inum, cutoff * cutoff, ncell,
                            cell_start, cell_atoms, xs, numneigh, (const int *) nullptr, (int *) nullptr, d_info + 1);
-      hipLaunchKernelGGL(nb_iota, dim3((inum + T - 1) / T), dim3(T), 0, st, ilist, inum);
     }
     if ((e = hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, numneigh, first, inum + 1, st)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(d_info, first + inum, sizeof(int), hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;

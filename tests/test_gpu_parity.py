@@ -352,11 +352,17 @@ def _rows_as_sets(first, neigh):
     return [np.sort(neigh[first[i]:first[i + 1]]) for i in range(len(first) - 1)]
 
 
-@pytest.mark.parametrize("ncell,a,cut", [((4, 4, 4), 3.165, 7.0), ((3, 4, 5), 2.9, 5.5), ((2, 2, 2), 3.165, 7.0)])
-def test_device_neighbour_build_matches_host_list(ncell, a, cut):
+@pytest.mark.parametrize("ncell,a,cut,sort_path", [((4, 4, 4), 3.165, 7.0, False), ((3, 4, 5), 2.9, 5.5, False),
+                                                   ((2, 2, 2), 3.165, 7.0, False), ((3, 4, 5), 2.9, 5.5, True),
+                                                   ((6, 6, 6), 3.165, 3.0, False)])
+def test_device_neighbour_build_matches_host_list(ncell, a, cut, sort_path, monkeypatch):
     """the GPU-built full list holds, row by row, exactly the atoms of the host KD-tree list
-    (integer work: compared as sets, bit-exact), and forces computed from it match the oracle."""
+    (integer work: compared as sets, bit-exact), and forces computed from it match the oracle.  sort_path: the
+    placement by a stable radix sort that grids above 65,536 cells take (MTP_NB_SORT); the 3 A case has cells with
+    very few atoms and many cells."""
     import torch
+    if sort_path:
+        monkeypatch.setenv("MTP_NB_SORT", "1")
     s = _system(ncell, a=a, list_cutoff=cut)
     path = os.path.join(POT, "W_L8.mtp")
     pot = capi.Potential(path)
