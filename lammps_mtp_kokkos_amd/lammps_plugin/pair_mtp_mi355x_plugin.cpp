@@ -13,8 +13,9 @@
 //       [-I$LAMMPS_SOURCE_DIR/src/KOKKOS -I<kokkos include dirs>] -I$REPO/include pair_mtp_mi355x_plugin.cpp
 //       -L$REPO/lammps_mtp_kokkos_amd -lpair_mtp_mi355x -lmtp_mi355x -o libmtp_mi355x_lammps.so
 // It has not been compiled against LAMMPS here; INTEGRATION.md lists what to check first.  What IS done here: the
-// non-KOKKOS branch is compiled against a mock of the API surface it touches (tests/cpp/lammps_mock/, test scaffolding
-// written for this purpose) and driven through LAMMPS' call sequence on the GPU (tests/cpp/test_plugin_mock.cpp).
+// adapter is compiled against a mock of the API surface it touches (tests/cpp/lammps_mock/, test scaffolding written for
+// this purpose) and driven through LAMMPS' call sequence on the GPU (tests/cpp/test_plugin_mock.cpp) -- the LMP_KOKKOS
+// branch too, against a mock of the KOKKOS package's data classes on device memory (lammps_mock/kokkos_mock.h).
 #ifdef LAMMPS_SOURCE_DIR_AVAILABLE
 
 #include "atom.h"

@@ -266,3 +266,65 @@ def test_plugin_adapter_extrapolation_style_fix_pair_protocol(tmp_path):
     assert abs(float(pv) - mg) < 1e-9 * max(1, mg)
     g = np.array(lines[1:1 + s.nlocal], float)
     assert np.abs(g - want["grades"][: s.nlocal]).max() < 1e-9 * max(1, mg)
+
+
+PLUGIN_KK_EXE = os.path.join(ROOT, "tests", "cpp", "test_plugin_mock_kk")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("style,layout,extra", [("mtp/kk", "left", ["chunksize", "32768"]),
+                                                ("mtp/kk", "right", ["chunksize", "4096"]),
+                                                ("mtp/small/kk", "left", ["chunksize", "32768"])])
+def test_plugin_adapter_kokkos_branch_runs_on_device_resident_atoms_and_list(tmp_path, style, layout, extra):
+    """The adapter's LMP_KOKKOS branch, compiled against the mock of the KOKKOS package's data classes
+    (tests/cpp/lammps_mock/kokkos_mock.h) and run on device memory: x / f / type come from the dual views' device side
+    (the host copy of x holds NaN), the list from NeighListKokkos' padded d_neighbors(i, jj) in either Kokkos layout with
+    LAMMPS' special bits in the ids, everything on the execution space's stream (KOKKOS/pair_mtp_kokkos.cpp:231-240);
+    forces land in the device f, eng_vdwl / virial / eatom / vatom in the host arrays LAMMPS reads.  Also the data-manager
+    protocol: sync(Device, X|F|TYPE) before the force call, modified(Device, F) after it."""
+    from oracle.pyoracle import Oracle
+    _build()
+    pos, box = mtpgen.bcc_lattice(4, 4, 4)
+    s = periodic_system(pos, box, None, 7.0)
+    sysf, outf = str(tmp_path / "sys.txt"), str(tmp_path / "out.txt")
+    _write_system(sysf, s)
+    potf = os.path.join(POT, "W_L16.mtp")
+    r = subprocess.run([PLUGIN_KK_EXE, "runkk", style, sysf, outf, layout, potf] + extra, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = open(outf).read().split("\n")
+    e, cut, flags = lines[0].split()
+    assert float(cut) == 5.0 and flags == "11100"
+    vir = np.array(lines[1].split(), float)
+    arr = np.array([l.split() for l in lines[2:2 + s.nall]], float)
+    want = Oracle(potf).compute(s.x, s.types, s.ilist, s.first, s.neigh, eflag=3, vflag=4)
+    assert abs(float(e) - want["energy"]) < 1e-9
+    assert np.abs(arr[:, :3] - want["f"]).max() < 1e-9
+    assert np.abs(arr[:, 3] - want["eatom"]).max() < 1e-10
+    assert np.abs(arr[:, 4] - want["vatom"][:, 0]).max() < 1e-9
+    assert np.abs(vir - want["virial"]).max() < 1e-8 and np.abs(vir).max() > 1e-3
+    tag, synced, modified, sync_call, modified_call = lines[2 + s.nall].split()
+    assert tag == "kokkos" and int(synced) == (0x1 | 0x4 | 0x10) and int(modified) == 0x4      # X | F | TYPE, then F
+    assert 0 <= int(sync_call) < int(modified_call)
+
+
+@pytest.mark.gpu
+def test_plugin_adapter_kokkos_branch_extrapolation_style(tmp_path):
+    """mtp/extrapolation/kk through the KOKKOS branch: grades stay on the device until extract_peratom asks for them
+    (KOKKOS/pair_mtp_extrapolation_kokkos.cpp:223-243)."""
+    from oracle.pyoracle import Oracle
+    _build()
+    pos, box = mtpgen.bcc_lattice(3, 3, 3)
+    s = periodic_system(pos, box, None, 7.0)
+    sysf, outf = str(tmp_path / "sys.txt"), str(tmp_path / "out.txt")
+    _write_system(sysf, s)
+    potf = os.path.join(POT, "W_L16_nbh.almtp")
+    want = Oracle(potf, selection=True).compute(s.x, s.types, s.ilist, s.first, s.neigh, extrapolation=True)
+    r = subprocess.run([PLUGIN_KK_EXE, "runkk", "mtp/extrapolation/kk", sysf, outf, "left", potf, "chunksize", "32768"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = open(outf).read().split("\n")
+    e, e_first, pv, nextra = lines[0].split()
+    mg = want["max_grade"]
+    assert abs(float(e) - want["energy"]) < 1e-9 and abs(float(e_first) - want["energy"]) < 1e-9 and nextra == "1"
+    assert abs(float(pv) - mg) < 1e-9 * max(1, mg)
+    g = np.array(lines[1:1 + s.nlocal], float)
+    assert np.abs(g - want["grades"][: s.nlocal]).max() < 1e-9 * max(1, mg)
