@@ -517,6 +517,7 @@ int mtp_potential::finalize(std::string &err)
     }
   }
   const int leaf_row0 = level_offset[(size_t) nlev - 1];   // first (padded) row of the leaf block
+  int blocks_ahead = -1;   // head x tail blocks of the basic-moment pass, counted before they are built (search effort)
   if (A >= 2 && !rows_by_level.empty() && !std::getenv("MTP_NO_RENUMBER")) {
     struct Access {
       int nbk, w;
@@ -557,7 +558,48 @@ int mtp_potential::finalize(std::string &err)
       return c;
     };
     const long long cost_before = total_cost();
-    for (int round = 0; round < 2; round++) {   // (load-time budget: ~0.2 s at level 16, ~2 s at level 20)
+    // Search effort.  Potentials whose product passes run row per lane (the narrow lane grids: up to level 16) pay every
+    // modelled collision in ds_add_f64 cycles, the busiest pipe of their kernel: eight rounds of four times the proposals
+    // (about 10 s at level 16, once per potential load) take the model from 403 to 335 extra cycles per atom and the force
+    // call from 0.4322 to 0.4272 ms (same box, alternating runs).  The wide grids run the gather programs, which have
+    // their own refinement below: two rounds.  MTP_BANK_ROUNDS / MTP_BANK_SCALE override (tests use two rounds).
+    // (row per lane <=> at most 32 head x tail blocks in the basic-moment pass, mtp_pick_fwd_shape; the blocks are built
+    // further down, from the numbering found here, so their number is counted ahead: per tail degree j the slots with
+    // nu >= j in threes times the (b, c) pairs in threes, blocks without a basic left out)
+    blocks_ahead = 0;
+    {
+      std::vector<uint8_t> have((size_t) 16 * 16 * 16 * 16, 0), slot_used((size_t) 16 * 16, 0);
+      int Pmax = 0;
+      for (int i = 0; i < B; i++) {
+        const int32_t *q = &alpha_index_basic[4 * (size_t) i];
+        if (q[0] > 15 || q[1] > 15 || q[2] > 15 || q[3] > 15 || q[1] + q[2] + q[3] > 15) continue;   // (refused further down)
+        have[(((size_t) q[0] * 16 + q[1]) * 16 + q[2]) * 16 + q[3]] = 1;
+        slot_used[(size_t) q[0] * 16 + (q[1] + q[2] + q[3])] = 1;
+        Pmax = std::max(Pmax, q[1] + q[2] + q[3] + 1);
+      }
+      std::vector<std::pair<int, int>> slots;   // (mu, nu) in the order they are numbered below: nu ascending, then mu
+      for (int nu = 0; nu < Pmax; nu++)
+        for (int mu = 0; mu < 16; mu++)
+          if (slot_used[(size_t) mu * 16 + nu]) slots.push_back({mu, nu});
+      for (int j = 0; j < Pmax; j++) {
+        std::vector<std::pair<int, int>> heads;   // (slot index, a)
+        for (size_t sidx = 0; sidx < slots.size(); sidx++)
+          if (slots[sidx].second >= j) heads.push_back({(int) sidx, slots[sidx].second - j});
+        for (size_t h0 = 0; h0 < heads.size(); h0 += 3)
+          for (int t0 = 0; t0 <= j; t0 += 3) {
+            bool any = false;
+            for (size_t h = h0; h < h0 + 3 && h < heads.size(); h++)
+              for (int c = t0; c < t0 + 3 && c <= j; c++)
+                any |= have[(((size_t) slots[(size_t) heads[h].first].first * 16 + heads[h].second) * 16 + (j - c)) * 16 + c] != 0;
+            blocks_ahead += any;
+          }
+      }
+    }
+    const bool row_per_lane = blocks_ahead <= 32;
+    int bank_rounds = row_per_lane ? 8 : 2, bank_scale = row_per_lane ? 4 : 1;
+    if (const char *e = std::getenv("MTP_BANK_ROUNDS")) bank_rounds = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("MTP_BANK_SCALE")) bank_scale = std::max(1, std::atoi(e));
+    for (int round = 0; round < bank_rounds; round++) {
       // ---- (a) renumber moments, rows fixed ----------------------------------------------------------
       std::vector<Access> acc;
       // moment (file index) -> (access, weight of the moment in it: 1 for reads, its row count for adds), ascending
@@ -615,9 +657,16 @@ int mtp_potential::finalize(std::string &err)
           hist[(size_t) id * 32 + t] = (uint8_t) (hist[(size_t) id * 32 + t] + k - k2);
         }
       };
-      const long long trials = std::min<long long>(200ll * A, 300000ll);
+      const long long trials = bank_scale * std::min<long long>(200ll * A, 300000ll);
       for (long long t = 0; t < trials; t++) {
-        const int m1 = (int) (next() % (uint32_t) A);
+        // three proposals in four start from a moment some row uses (weighted by use: the often-used moments are the ones
+        // that collide), the rest from any moment
+        int m1 = (int) (next() % (uint32_t) A);
+        if ((next() & 3) != 0) {
+          const MtpRow &pr = rows_by_level[next() % (uint32_t) rows_by_level.size()];
+          const uint32_t st = next() % 3u;
+          m1 = st == 0 ? pr.a0 : (st == 1 ? pr.a1 : pr.a3);
+        }
         const std::vector<int> &cls = cls_members[m1 < B ? 0 : (leaf[m1] ? 2 : 1)];   // numbers swap inside a class only
         if (cls.size() < 2) continue;
         const int m2 = cls[next() % (uint32_t) cls.size()];
@@ -630,12 +679,16 @@ int mtp_potential::finalize(std::string &err)
       }
       // ---- (b) swap rows inside a level (they commute), numbering fixed -----------------------------------
       const int nlev2 = (int) level_offset.size() - 1;
-      const long long rtrials = std::min<long long>(100ll * (long long) rows_by_level.size(), 250000ll);
+      const long long rtrials = bank_scale * std::min<long long>(100ll * (long long) rows_by_level.size(), 250000ll);
       for (long long t = 0; t < rtrials; t++) {
         const int l = (int) (next() % (uint32_t) nlev2);
         const int b = level_offset[l], n = level_offset[l + 1] - b;
         if (n < 2) continue;
-        const int r1 = b + (int) (next() % (uint32_t) n), r2 = b + (int) (next() % (uint32_t) n);
+        // the first row comes from a 16-row group that has a collision (four tries), its partner from anywhere in the level
+        int r1 = b + (int) (next() % (uint32_t) n);
+        for (int tries = 0; tries < 4 && group_cost(r1 / 16 * 16, 16, 16, w_add, false) == 0; tries++)
+          r1 = b + (int) (next() % (uint32_t) n);
+        const int r2 = b + (int) (next() % (uint32_t) n);
         if (r1 / 16 == r2 / 16) continue;   // same add group (hence same read group): nothing changes
         auto local = [&]() {
           int c = group_cost(r1 / 16 * 16, 16, 16, w_add, false) + group_cost(r2 / 16 * 16, 16, 16, w_add, false);
@@ -648,9 +701,42 @@ int mtp_potential::finalize(std::string &err)
         if (local() >= c0) std::swap(rows_by_level[(size_t) r1], rows_by_level[(size_t) r2]);
       }
     }
-    if (std::getenv("MTP_DEBUG_BANKS"))
-      std::fprintf(stderr, "mtp: LDS bank model of the product passes: %lld -> %lld extra cycles per atom\n", cost_before,
-                   total_cost());
+    if (std::getenv("MTP_DEBUG_BANKS")) {
+      long long cr = 0, ca = 0;
+      for (size_t r0 = 0; r0 < rows_by_level.size(); r0 += 32) cr += group_cost((int) r0, 32, 32, w_read, true);
+      for (size_t r0 = 0; r0 < rows_by_level.size(); r0 += 16) ca += group_cost((int) r0, 16, 16, w_add, false);
+      // adds split by stream (a0, a1: reverse pass; a3: forward) and into same-address / same-bank shares
+      long long same_addr[3] = {0, 0, 0}, same_bank[3] = {0, 0, 0};
+      for (size_t r0 = 0; r0 < rows_by_level.size(); r0 += 16)
+        for (int st = 0; st < ((int) r0 >= leaf_row0 ? 2 : 3); st++) {
+          int cnt_addr[16][16], ids[16][16], nid[16] = {0};
+          int h[16] = {0};
+          for (size_t r = r0; r < r0 + 16; r++) {
+            const MtpRow &row = rows_by_level[r];
+            const int m = moment_perm[st == 0 ? row.a0 : (st == 1 ? row.a1 : row.a3)], b = m % 16;
+            h[b]++;
+            int q = 0;
+            for (; q < nid[b]; q++)
+              if (ids[b][q] == m) break;
+            if (q == nid[b]) {
+              ids[b][q] = m;
+              cnt_addr[b][q] = 0;
+              nid[b]++;
+            }
+            cnt_addr[b][q]++;
+          }
+          for (int b = 0; b < 16; b++) {
+            int sa = 0;
+            for (int q = 0; q < nid[b]; q++) sa += cnt_addr[b][q] - 1;
+            same_addr[st] += sa;
+            same_bank[st] += (h[b] > 1 ? h[b] - 1 : 0) - sa;
+          }
+        }
+      std::fprintf(stderr, "mtp: LDS bank model of the product passes: %lld -> %lld extra cycles per atom (reads %lld, adds %lld); "
+                           "%d head x tail blocks, %d rounds x %d\n", cost_before, total_cost(), cr, ca, blocks_ahead, bank_rounds, bank_scale);
+      std::fprintf(stderr, "mtp:   adds, same address / other address on the bank: D[a0] %lld / %lld, D[a1] %lld / %lld, M[a3] %lld / %lld\n",
+                   same_addr[0], same_bank[0], same_addr[1], same_bank[1], same_addr[2], same_bank[2]);
+    }
   }
   for (MtpRow &row : rows_by_level) {
     row.a0 = moment_perm[row.a0];
@@ -802,6 +888,10 @@ int mtp_potential::finalize(std::string &err)
           err = "internal: basic moment not covered exactly once by the head x tail blocks";
           return MTP_ERR_TABLE;
         }
+      if (blocks_ahead >= 0 && blocks_ahead != fwd_block_count) {
+        err = "internal: the head x tail blocks counted ahead of the renumbering differ from the blocks built";
+        return MTP_ERR_TABLE;
+      }
     }
     // packed basic descriptors in LDS numbering (mtp_cvec_kernel pairs them with dbasic[k] = D[k])
     basic_pack_lds.assign((size_t) B, 0);

@@ -8,6 +8,9 @@ import tempfile
 
 import numpy as np
 
+os.environ.setdefault("MTP_BANK_ROUNDS", "2")   # (search effort of the LDS-bank numbering: a load-time / speed knob only)
+os.environ.setdefault("MTP_BANK_SCALE", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests._fuzz import fuzz_case  # noqa: E402

@@ -8,6 +8,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The library spends up to ~10 s per potential load on its LDS-bank search for the product rows (csrc/mtp_potential.cpp;
+# a performance matter only: every numbering gives the same results).  The suites load hundreds of potentials, so they run
+# with two rounds of it unless the caller set the knobs; tests/test_gpu_parity.py::test_production_bank_search_effort runs
+# the shipped default.
+os.environ.setdefault("MTP_BANK_ROUNDS", "2")
+os.environ.setdefault("MTP_BANK_SCALE", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box)")
 

@@ -71,6 +71,15 @@ def test_level16_432_atoms():
     _compare(os.path.join(POT, "W_L16.mtp"), _system((6, 6, 6)))
 
 
+def test_production_bank_search_effort(monkeypatch):
+    """The suites run with two rounds of the LDS-bank search (tests/conftest.py); this one loads the headline potential
+    with the shipped effort (eight rounds of four times the proposals for row-per-lane potentials) -- another numbering
+    of the moments and another order of the rows inside the levels, same results."""
+    monkeypatch.delenv("MTP_BANK_ROUNDS", raising=False)
+    monkeypatch.delenv("MTP_BANK_SCALE", raising=False)
+    _compare(os.path.join(POT, "W_L16.mtp"), _system((3, 3, 3)))
+
+
 def test_level20_two_species():
     _compare(os.path.join(POT, "WRe_L20.mtp"), _system((3, 3, 3), species=2))
 
